@@ -1,0 +1,142 @@
+/*
+ * crnn_hip.h -- C ABI of libcrnn_hip.so, the MI355X (gfx950) implementation of
+ * the reference's CRNN text-line recognition path.
+ *
+ * The reference (ClassesOver/ocr) has no native code: the path is Python +
+ * torch (crnn/network_torch.py, crnn/util.py).  Each entry point below names
+ * the reference interface it replaces; the Python class that mirrors
+ * `crnn.network_torch.CRNN` on top of this ABI is ocr_amd/crnn/network_hip.py
+ * and INTEGRATION.md shows the binding a maintainer adds to the reference.
+ *
+ * Conventions: plain pointers and sizes, no torch types.  Every function
+ * returns 0 on success or a negative crnn_status; nothing throws across the
+ * boundary.  The caller owns every buffer.  A handle is bound to one device
+ * and one HIP stream and is internally mutex-guarded, so the two gunicorn
+ * threads of a worker (gunicorn.conf.py:24) may share it.  Device state is
+ * created lazily on the first call that needs it, so a handle may be created
+ * before fork() (gunicorn preload_app, gunicorn.conf.py:57) and used after.
+ */
+#ifndef CRNN_HIP_H
+#define CRNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRNN_API __attribute__((visibility("default")))
+
+typedef struct crnn_handle crnn_handle;
+
+typedef enum {
+  CRNN_OK = 0,
+  CRNN_ERR_ARG = -1,      /* bad argument (null pointer, bad shape, missing tensor) */
+  CRNN_ERR_HIP = -2,      /* a HIP runtime call failed; see crnn_last_error */
+  CRNN_ERR_STATE = -3,    /* weights not loaded */
+  CRNN_ERR_ZERO_H = -4,   /* source height 0: ZeroDivisionError in crnn/util.py:7-8 */
+  CRNN_ERR_ZERO_W = -5,   /* resized width 0: Pillow's resize raises ValueError (crnn/util.py:10) */
+  CRNN_ERR_NOMEM = -6
+} crnn_status;
+
+/* Constructor arguments of CRNN(imgH, nc, nclass, nh, leakyRelu, lstmFlag, GPU, alphabet)
+ * -- crnn/network_torch.py:37; built at settings.py:45 as CRNN(32,1,nclass,256,False,LSTMFLAG,GPU,alphabet). */
+typedef struct {
+  int32_t img_h;      /* 32 */
+  int32_t nc;         /* 1 */
+  int32_t nclass;     /* len(alphabet)+1 */
+  int32_t nh;         /* 256 */
+  int32_t leaky_relu; /* leakyRelu */
+  int32_t lstm;       /* lstmFlag */
+  int32_t device;     /* HIP device ordinal (config.GPUID) */
+  int32_t reserved;
+} crnn_config;
+
+/* One entry of the flat state dict CRNN.load_weights reads (network_torch.py:110-117):
+ * names as in the reference module ("cnn.conv0.weight", "rnn.0.rnn.weight_ih_l0_reverse", ...;
+ * a leading "module." is stripped like :115), fp32, row-major, torch shapes. */
+typedef struct {
+  const char* name;
+  const float* data;
+  int32_t ndim;
+  int64_t shape[4];
+} crnn_tensor;
+
+/* CRNN.__init__ (network_torch.py:37-86).  Allocates host state only. */
+CRNN_API int crnn_create(const crnn_config* cfg, crnn_handle** out);
+
+/* CRNN.load_weights (network_torch.py:110-120): takes the named host tensors (borrowed for
+ * the call), folds BatchNorm (eval mode, eps 1e-5) into the preceding conv, reorders conv
+ * weights to (ky,kx,ci), packs W_hh for the recurrent kernel; uploaded to the device lazily. */
+CRNN_API int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n);
+
+/* crnn/util.py:6-9: scale = H/imgH; w = int(W/scale).  Returns w, or a negative status. */
+CRNN_API int crnn_resized_width(const crnn_handle* h, int32_t src_w, int32_t src_h);
+
+/* T = number of CTC timesteps for an input of width w (conv stack of network_torch.py:66-78). */
+CRNN_API int crnn_out_len(int32_t w);
+
+/* CRNN.ocr's colour conversion (network_torch.py:124) + resizeNormalize (util.py:6-13) for n
+ * host images (uint8; channels[i] = 3 for BGR rows as the detectors pass them, 1 for PIL 'L').
+ * Writes normalised fp32 [n,32,wp] (zero right padding) to out_host and the resized widths to
+ * out_w.  wp must be >= every resized width.  Debug/parity entry point. */
+CRNN_API int crnn_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights,
+                    const int32_t* widths, const int32_t* row_strides, const int32_t* channels,
+                    int32_t n, int32_t wp, float* out_host, int32_t* out_w);
+
+/* pad_mode for crnn_predict_batch */
+#define CRNN_PAD_PER_LINE 0 /* every line decoded exactly as CRNN.predict would decode it alone */
+#define CRNN_PAD_REFERENCE 1 /* CRNN.predict_batch semantics (network_torch.py:179-196): zero
+                                right-padding to the widest line, all T of the padded width decoded */
+
+/* CRNN.predict / predict_job / predict_batch (network_torch.py:130-200) for n host images.
+ *   out_raw   [n,tmax] int32  arg-max class per timestep (preds.max(2), :144); may be NULL
+ *   out_lab   [n,tmax] int32  greedy-CTC-collapsed alphabet positions (class-1), util.py:16-22
+ *   out_len   [n]      int32  number of labels per line; lines with resized width < 8 get 0
+ *                             (the '' of :141-142)
+ *   out_t     [n]      int32  timesteps decoded per line; may be NULL
+ *   out_logits [n,tmax,nclass] fp32 or NULL (debug: the forward() output, batch-major)
+ * tmax must be >= crnn_out_len(widest resized line).  Lines may have different sizes. */
+CRNN_API int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights,
+                       const int32_t* widths, const int32_t* row_strides, const int32_t* channels,
+                       int32_t n, int32_t pad_mode, int32_t tmax, int32_t* out_raw, int32_t* out_lab,
+                       int32_t* out_len, int32_t* out_t, float* out_logits);
+
+/* The same path for lines already resident in device memory at height 32 (the layout the
+ * width-bucketing scheduler and bench.py use): d_gray uint8 [n,32,w] device pointer; widths
+ * host int32[n] (valid width of each line, <= w) or NULL when every line is w wide.
+ * Outputs are DEVICE pointers: d_lab [n,T] int32, d_len [n] int32, d_raw [n,T] int32 or NULL,
+ * with T = crnn_out_len(w).  Runs asynchronously on the handle's stream unless sync != 0.
+ * No reference counterpart (the reference never keeps data on a device). */
+CRNN_API int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_t w,
+                        const int32_t* widths, int32_t* d_raw, int32_t* d_lab, int32_t* d_len,
+                        int32_t sync);
+
+/* Debug taps for layer-by-layer parity: runs crnn_forward_device's network on normalised fp32
+ * host input x [n,32,w] and copies stage `stage` (0 pool0, 1 pool1, 2 relu2, 3 pool2, 4 relu4,
+ * 5 pool3, 6 relu6/sequence, 7 lstm0 out, 8 lstm0 recurrent, 9 lstm1 recurrent, 10 logits),
+ * NHWC / batch-major as stored on the device, to out_host (capacity out_floats). */
+CRNN_API int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const int32_t* widths,
+                     int32_t stage, float* out_host, int64_t out_floats);
+
+/* Blocks until everything queued on the handle's stream has finished. */
+CRNN_API int crnn_synchronize(crnn_handle* h);
+
+/* The HIP stream (hipStream_t as void*) the handle launches on, for callers that time with
+ * HIP events or order their own work against it. */
+CRNN_API void* crnn_stream(crnn_handle* h);
+
+/* Device time of the most recent crnn_forward_device / crnn_predict_batch in ms (HIP events
+ * on the handle's stream), split by stage: [0] preprocess, [1] conv stack, [2] lstm+linear,
+ * [3] argmax+ctc, [4] total.  Valid after crnn_synchronize. */
+CRNN_API int crnn_last_timing(crnn_handle* h, float ms[5]);
+
+/* Message of the last failing call on this handle (never NULL). */
+CRNN_API const char* crnn_last_error(const crnn_handle* h);
+
+CRNN_API void crnn_destroy(crnn_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRNN_HIP_H */

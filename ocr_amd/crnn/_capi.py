@@ -1,0 +1,118 @@
+"""ctypes binding of ocr_amd/libcrnn_hip.so (include/crnn_hip.h).
+
+The library is the product; there is no Python/CPU compute fallback.  If the
+shared object is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libcrnn_hip.so")
+
+CRNN_OK = 0
+CRNN_ERR_ARG, CRNN_ERR_HIP, CRNN_ERR_STATE, CRNN_ERR_ZERO_H, CRNN_ERR_ZERO_W, CRNN_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+PAD_PER_LINE, PAD_REFERENCE = 0, 1
+
+SYMBOLS = ["crnn_create", "crnn_load_weights", "crnn_resized_width", "crnn_out_len", "crnn_preprocess",
+           "crnn_predict_batch", "crnn_forward_device", "crnn_debug_stage", "crnn_synchronize", "crnn_stream",
+           "crnn_last_timing", "crnn_last_error", "crnn_destroy"]
+
+
+class Config(C.Structure):
+    _fields_ = [("img_h", C.c_int32), ("nc", C.c_int32), ("nclass", C.c_int32), ("nh", C.c_int32),
+                ("leaky_relu", C.c_int32), ("lstm", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "ocr_amd/libcrnn_hip.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ocr_amd/csrc` (hipcc, gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_int32)
+    L.crnn_create.restype = C.c_int
+    L.crnn_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.crnn_load_weights.restype = C.c_int
+    L.crnn_load_weights.argtypes = [vp, C.POINTER(Tensor), i32]
+    L.crnn_resized_width.restype = C.c_int
+    L.crnn_resized_width.argtypes = [vp, i32, i32]
+    L.crnn_out_len.restype = C.c_int
+    L.crnn_out_len.argtypes = [i32]
+    L.crnn_preprocess.restype = C.c_int
+    L.crnn_preprocess.argtypes = [vp, C.POINTER(vp), i32p, i32p, i32p, i32p, i32, i32, vp, i32p]
+    L.crnn_predict_batch.restype = C.c_int
+    L.crnn_predict_batch.argtypes = [vp, C.POINTER(vp), i32p, i32p, i32p, i32p, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.crnn_forward_device.restype = C.c_int
+    L.crnn_forward_device.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i32]
+    L.crnn_debug_stage.restype = C.c_int
+    L.crnn_debug_stage.argtypes = [vp, vp, i32, i32, vp, i32, vp, C.c_int64]
+    L.crnn_synchronize.restype = C.c_int
+    L.crnn_synchronize.argtypes = [vp]
+    L.crnn_stream.restype = vp
+    L.crnn_stream.argtypes = [vp]
+    L.crnn_last_timing.restype = C.c_int
+    L.crnn_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
+    L.crnn_last_error.restype = C.c_char_p
+    L.crnn_last_error.argtypes = [vp]
+    L.crnn_destroy.restype = None
+    L.crnn_destroy.argtypes = [vp]
+    _lib = L
+    return L
+
+
+class CrnnError(RuntimeError):
+    pass
+
+
+def check(handle, rc):
+    """Map a crnn_status to the exception the reference would raise at that point."""
+    if rc >= 0:
+        return rc
+    msg = lib().crnn_last_error(handle).decode("utf-8", "replace") if handle else "crnn error"
+    if rc == CRNN_ERR_ZERO_H:
+        raise ZeroDivisionError("float division by zero")  # util.py:8 on a zero-height image
+    if rc == CRNN_ERR_ZERO_W:
+        raise ValueError("height and width must be > 0")  # Pillow's resize, util.py:10
+    if rc == CRNN_ERR_ARG:
+        raise ValueError(msg)
+    if rc == CRNN_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise CrnnError("%s (status %d)" % (msg, rc))
+
+
+class ImageList:
+    """uint8 numpy images (HxW gray or HxWx3 BGR, rows may be strided) as the ABI's parallel arrays."""
+
+    def __init__(self, images):
+        self.keep = []
+        n = len(images)
+        self.n = n
+        self.ptrs = (C.c_void_p * n)()
+        self.h = (C.c_int32 * n)()
+        self.w = (C.c_int32 * n)()
+        self.stride = (C.c_int32 * n)()
+        self.ch = (C.c_int32 * n)()
+        for i, a in enumerate(images):
+            a = np.asarray(a)
+            if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+                raise ValueError("image %d: expected uint8 HxW (gray) or HxWx3 (BGR), got %s %s" % (i, a.dtype, a.shape))
+            ch = 1 if a.ndim == 2 else 3
+            ok = a.size == 0 or (a.strides[1] == ch and (ch == 1 or a.strides[2] == 1) and a.strides[0] >= a.shape[1] * ch)
+            if not ok:
+                a = np.ascontiguousarray(a)
+            self.keep.append(a)
+            self.ptrs[i] = a.ctypes.data
+            self.h[i], self.w[i], self.ch[i] = a.shape[0], a.shape[1], ch
+            self.stride[i] = a.strides[0] if a.size else a.shape[1] * ch

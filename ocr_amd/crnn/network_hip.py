@@ -1,0 +1,226 @@
+"""MI355X drop-in for the reference's ``crnn/network_torch.py``.
+
+``CRNN`` keeps the reference class's constructor and method signatures
+(``network_torch.py:37,110,122,130,149,157``) so that ``settings.py:45-51``
+(``crnn = CRNN(32, 1, nclass, 256, leakyRelu=False, lstmFlag=LSTMFLAG, GPU=GPU,
+alphabet=alphabet)``; ``ocr_predict = crnn.ocr``) and every caller above it
+(``obj_det/ocr_context.py:28``) work unchanged.  All arithmetic runs in the HIP
+library behind ``include/crnn_hip.h``; this file only marshals buffers and
+turns label indices into text.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from .util import labels_to_text
+
+
+def _as_gray_array(image):
+    """PIL 'L' image (what the reference's predict receives) or a uint8 HxW array."""
+    if hasattr(image, "mode") and hasattr(image, "size"):
+        if image.mode != "L":
+            # the reference's view(1,1,H,W) at network_torch.py:139 fails for multi-band images
+            raise ValueError("CRNN.predict expects a PIL image of mode 'L', got %r" % (image.mode,))
+        if image.size[1] == 0:
+            raise ZeroDivisionError("float division by zero")  # util.py:7-8
+        if image.size[0] == 0:
+            raise ValueError("height and width must be > 0")
+        return np.asarray(image)
+    a = np.asarray(image)
+    if a.ndim != 2 or a.dtype != np.uint8:
+        raise ValueError("expected a PIL 'L' image or a uint8 HxW array")
+    return a
+
+
+class CRNN(object):
+    """Same surface as ``crnn.network_torch.CRNN``; inference only."""
+
+    def __init__(self, imgH, nc, nclass, nh, leakyRelu=False, lstmFlag=True, GPU=False, alphabet=None, device=None):
+        assert imgH % 16 == 0, 'imgH has to be a multiple of 16'
+        if imgH != 32 or nc != 1 or nh != 256:
+            raise ValueError("the HIP path implements the shipped configuration: imgH=32, nc=1, nh=256")
+        self.lstmFlag = lstmFlag
+        self.GPU = GPU
+        self.alphabet = alphabet
+        self.nclass = nclass
+        if device is None:
+            device = int(os.environ.get("CRNN_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self.device = device
+        self._lib = _capi.lib()
+        cfg = _capi.Config(imgH, nc, nclass, nh, int(bool(leakyRelu)), int(bool(lstmFlag)), device, 0)
+        h = C.c_void_p()
+        rc = self._lib.crnn_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise ValueError("crnn_create failed (status %d)" % rc)
+        self._h = h
+        self._alpha_cp = None
+        if alphabet is not None:
+            self._alpha_cp = np.frombuffer(alphabet.encode("utf-32-le"), dtype="<u4")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.crnn_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict):
+        """Flat name -> tensor mapping with the reference's keys (numpy arrays or torch tensors)."""
+        keep, arr = [], (_capi.Tensor * len(state_dict))()
+        n = 0
+        for k, v in state_dict.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            if hasattr(v, "detach"):
+                v = v.detach().cpu().numpy()
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            keep.append(a)
+            arr[n].name = k.encode("utf-8")
+            arr[n].data = a.ctypes.data_as(C.POINTER(C.c_float))
+            arr[n].ndim = a.ndim
+            for i, s in enumerate(a.shape):
+                arr[n].shape[i] = s
+            n += 1
+        _capi.check(self._h, self._lib.crnn_load_weights(self._h, arr, n))
+        return self
+
+    def load_weights(self, path):
+        """network_torch.py:110-120: a flat ``.pth`` state dict, keys optionally prefixed ``module.``."""
+        import torch  # tensor plumbing only: reads the checkpoint
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        self.load_state_dict({k: v for k, v in sd.items()})
+
+    def eval(self):
+        return self
+
+    # --------------------------------------------------------------- inference
+    def _run(self, images, pad_mode, want_raw=False, want_logits=False):
+        il = _capi.ImageList(images)
+        n = il.n
+        wmax = 0
+        for i in range(n):
+            w = _capi.check(self._h, self._lib.crnn_resized_width(self._h, il.w[i], il.h[i]))
+            if w <= 0:
+                raise ValueError("height and width must be > 0")
+            wmax = max(wmax, w)
+        tmax = max(1, self._lib.crnn_out_len(wmax))
+        lab = np.zeros((n, tmax), np.int32)
+        ln = np.zeros(n, np.int32)
+        tt = np.zeros(n, np.int32)
+        raw = np.zeros((n, tmax), np.int32) if want_raw else None
+        logits = np.zeros((n, tmax, self.nclass), np.float32) if want_logits else None
+        rc = self._lib.crnn_predict_batch(
+            self._h, il.ptrs, il.h, il.w, il.stride, il.ch, n, pad_mode, tmax,
+            raw.ctypes.data if want_raw else None, lab.ctypes.data, ln.ctypes.data, tt.ctypes.data,
+            logits.ctypes.data if want_logits else None)
+        _capi.check(self._h, rc)
+        return lab, ln, tt, raw, logits
+
+    def _texts(self, lab, ln):
+        return [labels_to_text(lab[i, :ln[i]], self.alphabet, self._alpha_cp) for i in range(len(ln))]
+
+    def ocr(self, image):
+        """network_torch.py:122-128: HxWx3 uint8 BGR crop (a view into the page is fine) -> text."""
+        a = np.asarray(image)
+        if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8 or a.size == 0:
+            # cv2.cvtColor(image, COLOR_BGR2RGB) raises on anything else (:124)
+            raise ValueError("CRNN.ocr expects a non-empty HxWx3 uint8 BGR array, got %s %s" % (a.dtype, a.shape))
+        lab, ln, _, _, _ = self._run([a], _capi.PAD_PER_LINE)
+        return self._texts(lab, ln)[0]
+
+    def predict(self, image):
+        """network_torch.py:130-147: PIL 'L' image -> text ('' when the resized width is < 8)."""
+        lab, ln, _, _, _ = self._run([_as_gray_array(image)], _capi.PAD_PER_LINE)
+        return self._texts(lab, ln)[0]
+
+    def predict_job(self, boxes):
+        """network_torch.py:149-155: per-box predict; results are what predict gives each box alone."""
+        if len(boxes) == 0:
+            return boxes
+        texts = self.predict_lines([b['img'] for b in boxes])
+        for b, t in zip(boxes, texts):
+            b['text'] = t
+        return boxes
+
+    def predict_batch(self, boxes, batch_size=1):
+        """network_torch.py:157-200 with its exact semantics: chunks of ``batch_size`` boxes, each
+        chunk zero-right-padded to its widest line and all timesteps of the padded width decoded."""
+        N = len(boxes)
+        res = []
+        for i in range(0, N, batch_size):
+            imgs = [_as_gray_array(b['img']) for b in boxes[i:i + batch_size]]
+            lab, ln, _, _, _ = self._run(imgs, _capi.PAD_REFERENCE)
+            res.extend(self._texts(lab, ln))
+        for i in range(N):
+            boxes[i]['text'] = res[i]
+        return boxes
+
+    # ------------------------------------------------ batched, predict-exact API
+    def predict_lines(self, images, max_batch=256, width_spread=1.25):
+        """Texts of many lines, each identical to ``predict`` on that line alone.
+
+        Lines are sorted by resized width and cut into buckets (at most ``max_batch`` lines, widest
+        / narrowest <= ``width_spread``); each bucket is one padded device batch with per-line width
+        masks.  ``images``: PIL 'L' images, uint8 HxW arrays or HxWx3 BGR arrays."""
+        arrs = []
+        for im in images:
+            a = np.asarray(im) if not (hasattr(im, "mode") and hasattr(im, "size")) else _as_gray_array(im)
+            arrs.append(a)
+        from .batching import width_buckets
+        widths = []
+        for a in arrs:
+            if a.ndim < 2 or a.shape[0] == 0:
+                raise ZeroDivisionError("float division by zero")
+            widths.append(_capi.check(self._h, self._lib.crnn_resized_width(self._h, a.shape[1], a.shape[0])))
+        out = [None] * len(arrs)
+        for bucket in width_buckets(widths, max_batch, width_spread):
+            lab, ln, _, _, _ = self._run([arrs[i] for i in bucket], _capi.PAD_PER_LINE)
+            for i, t in zip(bucket, self._texts(lab, ln)):
+                out[i] = t
+        return out
+
+    # ------------------------------------------------------------- debug / test
+    def forward_logits(self, images, pad_mode=_capi.PAD_PER_LINE):
+        """(raw argmax [n,tmax], T per line, logits [n,tmax,nclass]) for parity tests."""
+        lab, ln, tt, raw, logits = self._run(images, pad_mode, want_raw=True, want_logits=True)
+        return raw, tt, logits, lab, ln
+
+    def preprocess(self, images):
+        """resizeNormalize of each image through the HIP kernels: list of float32 [32,w] arrays."""
+        il = _capi.ImageList(images)
+        n = il.n
+        ws = [_capi.check(self._h, self._lib.crnn_resized_width(self._h, il.w[i], il.h[i])) for i in range(n)]
+        if min(ws) <= 0:
+            raise ValueError("height and width must be > 0")
+        wp = max(ws)
+        out = np.empty((n, 32, wp), np.float32)
+        ow = (C.c_int32 * n)()
+        _capi.check(self._h, self._lib.crnn_preprocess(self._h, il.ptrs, il.h, il.w, il.stride, il.ch, n, wp,
+                                                       out.ctypes.data, ow))
+        return [out[i, :, :ow[i]].copy() for i in range(n)]
+
+    def debug_stage(self, x, stage, widths=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n, hh, w = x.shape
+        assert hh == 32
+        w1, w2 = w // 2, w // 2 // 2
+        T = w2 + 1
+        shapes = [(n, 16, w1, 64), (n, 8, w2, 128), (n, 8, w2, 256), (n, 4, w2 + 1, 256), (n, 4, w2 + 1, 512),
+                  (n, 2, w2 + 2, 512), (n, T, 512), (n, T, 256), (n, T, 512), (n, T, 512), (n, T, self.nclass)]
+        out = np.empty(shapes[stage], np.float32)
+        wv = None
+        if widths is not None:
+            wv = np.ascontiguousarray(widths, dtype=np.int32)
+        rc = self._lib.crnn_debug_stage(self._h, x.ctypes.data, n, w, wv.ctypes.data if wv is not None else None,
+                                        stage, out.ctypes.data, out.size)
+        _capi.check(self._h, rc)
+        return out
+
+    def timing(self):
+        ms = (C.c_float * 5)()
+        _capi.check(self._h, self._lib.crnn_last_timing(self._h, ms))
+        return dict(zip(("preprocess", "conv", "lstm_linear", "argmax_ctc", "total"), list(ms)))

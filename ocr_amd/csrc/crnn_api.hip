@@ -1,0 +1,718 @@
+// Host side of the C ABI declared in include/crnn_hip.h: weight repacking,
+// workspace management, Pillow-exact resize coefficients, kernel sequencing.
+// There is no CPU compute fallback here: without a HIP device every compute
+// entry point fails with CRNN_ERR_HIP.
+#include "../../include/crnn_hip.h"
+#include "crnn_kernels.h"
+
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace crnn;
+
+namespace {
+
+const int NM[7] = {64, 128, 256, 256, 512, 512, 512};
+const int KS[7] = {3, 3, 3, 3, 3, 3, 2};
+const bool HAS_BN[7] = {false, false, true, false, true, false, true};
+
+struct Geo {  // activation geometry for n lines of padded width W
+  int n, W, W1, W2, W3, W4, T;
+  explicit Geo(int n_ = 0, int W_ = 0) : n(n_), W(W_) {
+    W1 = W / 2; W2 = W1 / 2; W3 = W2 + 1; W4 = W3 + 1; T = W3;
+  }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct crnn_handle {
+  crnn_config cfg{};
+  std::mutex mu;
+  mutable std::string err = "";
+  bool loaded = false;
+
+  // host copies of the prepared weights (uploaded lazily, re-uploaded after fork)
+  std::vector<float> h_conv_w[7], h_conv_b[7];
+  std::vector<float> h_wih[2], h_bih[2], h_whhp[2], h_emb_w[2], h_emb_b[2], h_lin_w, h_lin_b;
+  float lut[256];
+
+  // device state
+  pid_t dev_pid = 0;
+  bool dev_ready = false;
+  bool weights_on_dev = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+  float* d_conv_w[7] = {};
+  float* d_conv_b[7] = {};
+  float* d_wih[2] = {};
+  float* d_bih[2] = {};
+  float* d_whhp[2] = {};
+  float* d_emb_w[2] = {};
+  float* d_emb_b[2] = {};
+  float* d_lin_w = nullptr;
+  float* d_lin_b = nullptr;
+  DevBuf arena;      // activations
+  DevBuf pre;        // preprocessing scratch (sources, temp, coefficients, jobs)
+  DevBuf io;         // per-call small buffers (widths, outputs for the host path)
+
+  // layout of the last run inside the arena (for crnn_debug_stage)
+  float* st[11] = {};
+  size_t st_floats[11] = {};
+};
+
+namespace {
+
+int fail(const crnn_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(h, CRNN_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
+  } while (0)
+
+int ensure_buf(crnn_handle* h, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return 0;
+  if (b.p) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 4096;
+  HIPCHK(h, hipMalloc(&b.p, want));
+  b.cap = want;
+  return 0;
+}
+
+int upload(crnn_handle* h, const std::vector<float>& src, float** dst) {
+  if (src.empty()) { *dst = nullptr; return 0; }
+  HIPCHK(h, hipMalloc((void**)dst, src.size() * sizeof(float)));
+  HIPCHK(h, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// Lazy per-process device initialisation (the model object is built before
+// gunicorn forks its workers; a HIP context does not survive fork()).
+int ensure_device(crnn_handle* h, bool need_weights = true) {
+  if (need_weights && !h->loaded)
+    return fail(h, CRNN_ERR_STATE, "weights not loaded (call crnn_load_weights first)");
+  if (h->dev_pid != getpid()) {
+    // first use in this process (or first use after a fork: the parent's pointers
+    // belong to its context -- drop them, do not free)
+    h->dev_ready = false;
+    h->weights_on_dev = false;
+    h->ev_valid = false;
+    h->arena = DevBuf(); h->pre = DevBuf(); h->io = DevBuf();
+  }
+  if (!h->dev_ready) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+      return fail(h, CRNN_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (h->cfg.device < 0 || h->cfg.device >= ndev) return fail(h, CRNN_ERR_ARG, "device ordinal out of range");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 5; i++) HIPCHK(h, hipEventCreate(&h->ev[i]));
+    upload_norm_lut(h->lut, h->stream);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->dev_pid = getpid();
+    h->dev_ready = true;
+  } else {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+  }
+  if (need_weights && !h->weights_on_dev) {
+    int rc;
+    for (int i = 0; i < 7; i++) {
+      if ((rc = upload(h, h->h_conv_w[i], &h->d_conv_w[i]))) return rc;
+      if ((rc = upload(h, h->h_conv_b[i], &h->d_conv_b[i]))) return rc;
+    }
+    for (int l = 0; l < 2; l++) {
+      if ((rc = upload(h, h->h_wih[l], &h->d_wih[l]))) return rc;
+      if ((rc = upload(h, h->h_bih[l], &h->d_bih[l]))) return rc;
+      if ((rc = upload(h, h->h_whhp[l], &h->d_whhp[l]))) return rc;
+      if ((rc = upload(h, h->h_emb_w[l], &h->d_emb_w[l]))) return rc;
+      if ((rc = upload(h, h->h_emb_b[l], &h->d_emb_b[l]))) return rc;
+    }
+    if ((rc = upload(h, h->h_lin_w, &h->d_lin_w))) return rc;
+    if ((rc = upload(h, h->h_lin_b, &h->d_lin_b))) return rc;
+    h->weights_on_dev = true;
+  }
+  return 0;
+}
+
+// ---- Pillow Resample.c coefficient computation (BILINEAR, support 1.0) ------
+// Same double-precision expressions as precompute_coeffs / normalize_coeffs_8bpc
+// so that the 22-bit fixed-point taps are bit-identical to Pillow's.
+// (no FMA contraction: Pillow's build evaluates these as separate double operations)
+int resample_coeffs(int in_size, int out_size, std::vector<int32_t>& bounds, std::vector<int32_t>& kk) {
+#pragma clang fp contract(off)
+  float in0 = 0.0f, in1 = (float)in_size;
+  double scale, filterscale;
+  filterscale = scale = (double)(in1 - in0) / out_size;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 1.0 * filterscale;
+  const int ksize = (int)std::ceil(support) * 2 + 1;
+  bounds.assign((size_t)out_size * 2, 0);
+  kk.assign((size_t)out_size * ksize, 0);
+  std::vector<double> k(ksize);
+  for (int xx = 0; xx < out_size; xx++) {
+    const double center = in0 + (xx + 0.5) * scale;
+    double ww = 0.0;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    for (int x = 0; x < xmax; x++) {
+      double v = (x + xmin - center + 0.5) * ss;
+      if (v < 0.0) v = -v;
+      const double w = v < 1.0 ? 1.0 - v : 0.0;
+      k[x] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; x++) {
+      if (ww != 0.0) k[x] /= ww;
+      const double c = k[x];
+      kk[(size_t)xx * ksize + x] = c < 0 ? (int32_t)(-0.5 + c * (1 << 22)) : (int32_t)(0.5 + c * (1 << 22));
+    }
+    bounds[xx * 2] = xmin;
+    bounds[xx * 2 + 1] = xmax;
+  }
+  return ksize;
+}
+
+int resized_width(int sw, int sh, int img_h) {
+#pragma clang fp contract(off)
+  const double scale = (double)sh * 1.0 / (double)img_h;
+  return (int)((double)sw / scale);
+}
+
+const float* find_tensor(const std::map<std::string, const crnn_tensor*>& m, const std::string& name,
+                         std::initializer_list<int64_t> shape, std::string& err) {
+  auto it = m.find(name);
+  if (it == m.end()) { err = "missing tensor " + name; return nullptr; }
+  const crnn_tensor* t = it->second;
+  if (!t->data || t->ndim != (int)shape.size()) { err = "bad rank for " + name; return nullptr; }
+  int i = 0;
+  for (int64_t s : shape)
+    if (t->shape[i++] != s) { err = "bad shape for " + name; return nullptr; }
+  return t->data;
+}
+
+// activation workspace: carve the arena for geometry g
+struct Plan {
+  float *x, *p0, *c1, *p1, *c2, *c3, *p2, *c4, *c5, *p3, *seq, *xp, *rec0, *mid, *rec1, *logits;
+  int32_t *wl;   // [8][n] per-layer width arrays
+  int32_t *raw;  // [n*T]
+  size_t bytes;
+};
+
+Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
+  Plan p{};
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    float* r = (float*)(base + off);
+    off += ((floats * 4 + 255) / 256) * 256;
+    return r;
+  };
+  const size_t n = g.n;
+  p.x = take(n * 32 * g.W);
+  p.p0 = take(n * 16 * g.W1 * 64);
+  p.c1 = take(n * 16 * g.W1 * 128);
+  p.p1 = take(n * 8 * g.W2 * 128);
+  p.c2 = take(n * 8 * g.W2 * 256);
+  p.c3 = take(n * 8 * g.W2 * 256);
+  p.p2 = take(n * 4 * g.W3 * 256);
+  p.c4 = take(n * 4 * g.W3 * 512);
+  p.c5 = take(n * 4 * g.W3 * 512);
+  p.p3 = take(n * 2 * g.W4 * 512);
+  p.seq = take(n * g.T * 512);
+  p.xp = take(n * g.T * 2048);
+  p.rec0 = take(n * g.T * 512);
+  p.mid = take(n * g.T * 256);
+  p.rec1 = take(n * g.T * 512);
+  p.logits = take(n * g.T * (size_t)h->cfg.nclass);
+  p.wl = (int32_t*)take(8 * n);
+  p.raw = (int32_t*)take(n * g.T);
+  p.bytes = off;
+  return p;
+}
+
+void gemm(crnn_handle* h, const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K) {
+  ConvGemm p{};
+  p.A = A; p.Wt = Wt; p.bias = bias; p.C = C; p.wvalid = nullptr;
+  p.M = M; p.N = N; p.K = K; p.ldc = N;
+  p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
+  launch_conv_gemm(p, h->stream);
+}
+
+void conv(crnn_handle* h, int layer, const float* A, float* C, const int32_t* wvalid, int n, int Hin, int Win,
+          int Cin, int Hout, int Wout) {
+  ConvGemm p{};
+  p.A = A; p.Wt = h->d_conv_w[layer]; p.bias = h->d_conv_b[layer]; p.C = C; p.wvalid = wvalid;
+  p.M = n * Hout * Wout; p.N = NM[layer]; p.K = KS[layer] * KS[layer] * Cin; p.ldc = NM[layer];
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
+  p.ks = KS[layer]; p.pad = KS[layer] == 3 ? 1 : 0;
+  p.act = h->cfg.leaky_relu ? 2 : 1;
+  launch_conv_gemm(p, h->stream);
+}
+
+// Runs the network on the normalised input already in plan.x.  widths: host
+// per-line valid widths or nullptr.  Outputs (device): plan.raw plus d_lab/d_len.
+int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widths, int32_t* d_lab,
+                int32_t* d_len) {
+  const int n = g.n;
+  const int act = h->cfg.leaky_relu ? 2 : 1;
+  const int32_t *m_p0 = nullptr, *m_c1 = nullptr, *m_w2 = nullptr, *m_w3 = nullptr, *tlen = nullptr;
+  if (widths) {
+    std::vector<int32_t> wl((size_t)8 * n);
+    for (int i = 0; i < n; i++) {
+      const int w = widths[i], w1 = w / 2, w2 = w1 / 2, w3 = w2 + 1;
+      wl[0 * n + i] = w1;            // valid pooled width after conv0+pool0
+      wl[1 * n + i] = 2 * w2;        // conv1 output columns that reach pool1
+      wl[2 * n + i] = w2;            // conv2, conv3
+      wl[3 * n + i] = w3;            // conv4, conv5 ; also T_i
+    }
+    HIPCHK(h, hipMemcpyAsync(p.wl, wl.data(), sizeof(int32_t) * 4 * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // wl is a stack temporary
+    m_p0 = p.wl; m_c1 = p.wl + n; m_w2 = p.wl + 2 * n; m_w3 = p.wl + 3 * n; tlen = m_w3;
+  }
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipEventRecord(h->ev[1], s));
+  launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
+  conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1);
+  launch_pool_2x2s2(p.c1, p.p1, n, 16, g.W1, 128, s);
+  conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2);
+  conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2);
+  launch_pool_2x2s21p01(p.c3, p.p2, n, 8, g.W2, 256, s);
+  conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3);
+  conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3);
+  launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
+  conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T);
+  HIPCHK(h, hipEventRecord(h->ev[2], s));
+  const int M = n * g.T;
+  if (h->cfg.lstm) {
+    gemm(h, p.seq, h->d_wih[0], h->d_bih[0], p.xp, M, 2048, 512);
+    launch_lstm_rec(p.xp, h->d_whhp[0], p.rec0, tlen, n, g.T, s);
+    gemm(h, p.rec0, h->d_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512);
+    gemm(h, p.mid, h->d_wih[1], h->d_bih[1], p.xp, M, 2048, 256);
+    launch_lstm_rec(p.xp, h->d_whhp[1], p.rec1, tlen, n, g.T, s);
+    gemm(h, p.rec1, h->d_emb_w[1], h->d_emb_b[1], p.logits, M, h->cfg.nclass, 512);
+  } else {
+    gemm(h, p.seq, h->d_lin_w, h->d_lin_b, p.logits, M, h->cfg.nclass, 512);
+  }
+  HIPCHK(h, hipEventRecord(h->ev[3], s));
+  launch_argmax(p.logits, p.raw, M, h->cfg.nclass, h->cfg.nclass, s);
+  launch_ctc(p.raw, tlen, d_lab, d_len, n, g.T, s);
+  HIPCHK(h, hipEventRecord(h->ev[4], s));
+  h->ev_valid = true;
+  HIPCHK(h, hipGetLastError());
+  // remember where the stages live
+  float* st[11] = {p.p0, p.p1, p.c2, p.p2, p.c4, p.p3, p.seq, p.mid, p.rec0, p.rec1, p.logits};
+  size_t sz[11] = {(size_t)n * 16 * g.W1 * 64, (size_t)n * 8 * g.W2 * 128, (size_t)n * 8 * g.W2 * 256,
+                   (size_t)n * 4 * g.W3 * 256, (size_t)n * 4 * g.W3 * 512, (size_t)n * 2 * g.W4 * 512,
+                   (size_t)M * 512, (size_t)M * 256, (size_t)M * 512, (size_t)M * 512,
+                   (size_t)M * h->cfg.nclass};
+  for (int i = 0; i < 11; i++) { h->st[i] = st[i]; h->st_floats[i] = sz[i]; }
+  return 0;
+}
+
+int prepare_plan(crnn_handle* h, const Geo& g, Plan& p) {
+  Plan probe = make_plan(h, g, nullptr);
+  int rc = ensure_buf(h, h->arena, probe.bytes);
+  if (rc) return rc;
+  p = make_plan(h, g, (char*)h->arena.p);
+  return 0;
+}
+
+// Gray conversion + Pillow-exact resize + normalise for a set of host images,
+// into d_x [nb,32,Wp].  sel lists the image indices to process, dw their
+// resized widths.
+int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
+                   const int32_t* row_strides, const int32_t* channels, const std::vector<int>& sel,
+                   const std::vector<int>& dw, int Wp, float* d_x) {
+  const int nb = (int)sel.size();
+  std::vector<ResizeJob> jobs(nb);
+  std::vector<int32_t> coef;
+  std::vector<int32_t> bh, kh, bv, kv;
+  size_t src_bytes = 0, tmp_bytes = 0;
+  int max_th = 1, max_dw = 1;
+  for (int j = 0; j < nb; j++) {
+    const int i = sel[j];
+    ResizeJob& J = jobs[j];
+    const int sh = heights[i], sw = widths[i], ch = channels[i];
+    J.sh = sh; J.sw = sw; J.ch = ch; J.dw = dw[j];
+    J.stride = sw * ch;  // repacked tightly on upload
+    J.src_off = (int64_t)src_bytes;
+    src_bytes += ((size_t)sh * J.stride + 15) / 16 * 16;
+    J.ksh = resample_coeffs(sw, J.dw, bh, kh);
+    J.ksv = resample_coeffs(sh, 32, bv, kv);
+    J.ybox_first = bv[0];
+    const int ybox_last = bv[2 * 31] + bv[2 * 31 + 1];
+    J.th = ybox_last - J.ybox_first;
+    for (int y = 0; y < 32; y++) bv[2 * y] -= J.ybox_first;
+    J.tmp_off = (int64_t)tmp_bytes;
+    tmp_bytes += ((size_t)J.th * J.dw + 15) / 16 * 16;
+    J.coef_off = (int64_t)coef.size();
+    coef.insert(coef.end(), bh.begin(), bh.end());
+    coef.insert(coef.end(), kh.begin(), kh.end());
+    coef.insert(coef.end(), bv.begin(), bv.end());
+    coef.insert(coef.end(), kv.begin(), kv.end());
+    if (J.th > max_th) max_th = J.th;
+    if (J.dw > max_dw) max_dw = J.dw;
+  }
+  // pack the sources (rows may be strided views of a page: ocr_context.py:307, vat_detect.py:318)
+  std::vector<uint8_t> src(src_bytes);
+  for (int j = 0; j < nb; j++) {
+    const int i = sel[j];
+    const size_t rowb = (size_t)widths[i] * channels[i];
+    for (int y = 0; y < heights[i]; y++)
+      memcpy(src.data() + jobs[j].src_off + y * rowb, imgs[i] + (size_t)y * row_strides[i], rowb);
+  }
+  const size_t a = (src_bytes + 255) / 256 * 256, b = (tmp_bytes + 255) / 256 * 256;
+  const size_t c = (coef.size() * 4 + 255) / 256 * 256, d = (jobs.size() * sizeof(ResizeJob) + 255) / 256 * 256;
+  int rc = ensure_buf(h, h->pre, a + b + c + d);
+  if (rc) return rc;
+  uint8_t* d_src = (uint8_t*)h->pre.p;
+  uint8_t* d_tmp = d_src + a;
+  int32_t* d_coef = (int32_t*)(d_tmp + b);
+  ResizeJob* d_jobs = (ResizeJob*)((char*)d_coef + c);
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipMemcpyAsync(d_src, src.data(), src_bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(d_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(ResizeJob), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipEventRecord(h->ev[0], s));
+  launch_resize_h(d_src, d_jobs, d_coef, d_tmp, nb, max_th, max_dw, s);
+  launch_resize_v(d_src, d_jobs, d_coef, d_tmp, d_x, nb, Wp, s);
+  HIPCHK(h, hipStreamSynchronize(s));  // host staging vectors go out of scope
+  return 0;
+}
+
+int check_images(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
+                 const int32_t* row_strides, const int32_t* channels, int n) {
+  if (!imgs || !heights || !widths || !row_strides || !channels) return fail(h, CRNN_ERR_ARG, "null image array");
+  for (int i = 0; i < n; i++) {
+    if (channels[i] != 1 && channels[i] != 3) return fail(h, CRNN_ERR_ARG, "channels must be 1 (gray) or 3 (BGR)");
+    if (heights[i] < 0 || widths[i] < 0) return fail(h, CRNN_ERR_ARG, "negative image size");
+    if (heights[i] == 0) return fail(h, CRNN_ERR_ZERO_H, "image height 0 (ZeroDivisionError in resizeNormalize)");
+    if (resized_width(widths[i], heights[i], 32) <= 0)
+      return fail(h, CRNN_ERR_ZERO_W, "resized width 0 (height and width must be > 0)");
+    if (!imgs[i]) return fail(h, CRNN_ERR_ARG, "null image pointer");
+    if (row_strides[i] < widths[i] * channels[i]) return fail(h, CRNN_ERR_ARG, "row stride smaller than a row");
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crnn_create(const crnn_config* cfg, crnn_handle** out) {
+  if (!cfg || !out) return CRNN_ERR_ARG;
+  *out = nullptr;
+  if (cfg->img_h != 32 || cfg->nc != 1 || cfg->nh != 256 || cfg->nclass < 2) return CRNN_ERR_ARG;
+  crnn_handle* h = new (std::nothrow) crnn_handle();
+  if (!h) return CRNN_ERR_NOMEM;
+  h->cfg = *cfg;
+  for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);
+  *out = h;
+  return 0;
+}
+
+int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!tensors || n <= 0) return fail(h, CRNN_ERR_ARG, "no tensors");
+  if (h->weights_on_dev) return fail(h, CRNN_ERR_STATE, "weights already on the device; create a new handle");
+  std::map<std::string, const crnn_tensor*> m;
+  for (int i = 0; i < n; i++) {
+    if (!tensors[i].name) return fail(h, CRNN_ERR_ARG, "tensor without a name");
+    std::string nm = tensors[i].name;
+    size_t pos;
+    while ((pos = nm.find("module.")) != std::string::npos) nm.erase(pos, 7);  // network_torch.py:115
+    m[nm] = &tensors[i];
+  }
+  std::string err;
+  const int nh = 256, nclass = h->cfg.nclass;
+  for (int i = 0; i < 7; i++) {
+    const int cin = i == 0 ? 1 : NM[i - 1], co = NM[i], k = KS[i];
+    const std::string pc = "cnn.conv" + std::to_string(i) + ".";
+    const float* w = find_tensor(m, pc + "weight", {co, cin, k, k}, err);
+    const float* b = w ? find_tensor(m, pc + "bias", {co}, err) : nullptr;
+    const float *g = nullptr, *bt = nullptr, *mu = nullptr, *var = nullptr;
+    if (b && HAS_BN[i]) {
+      const std::string pb = "cnn.batchnorm" + std::to_string(i) + ".";
+      g = find_tensor(m, pb + "weight", {co}, err);
+      bt = g ? find_tensor(m, pb + "bias", {co}, err) : nullptr;
+      mu = bt ? find_tensor(m, pb + "running_mean", {co}, err) : nullptr;
+      var = mu ? find_tensor(m, pb + "running_var", {co}, err) : nullptr;
+      if (!var) b = nullptr;
+    }
+    if (!b) return fail(h, CRNN_ERR_ARG, err);
+    // BatchNorm2d(eval): y = (x - mean) / sqrt(var + eps) * gamma + beta, folded into w, b
+    h->h_conv_w[i].assign((size_t)co * k * k * cin, 0.f);
+    h->h_conv_b[i].assign(co, 0.f);
+    for (int o = 0; o < co; o++) {
+      double sc = 1.0, sh = 0.0;
+      if (g) {
+        sc = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+        sh = (double)bt[o] - (double)mu[o] * sc;
+      }
+      h->h_conv_b[i][o] = (float)((double)b[o] * sc + sh);
+      for (int c = 0; c < cin; c++)
+        for (int ky = 0; ky < k; ky++)
+          for (int kx = 0; kx < k; kx++) {
+            const float v = (float)((double)w[(((size_t)o * cin + c) * k + ky) * k + kx] * sc);
+            if (i == 0)
+              h->h_conv_w[0][(size_t)(ky * 3 + kx) * 64 + o] = v;  // [tap][co] for the direct kernel
+            else
+              h->h_conv_w[i][(((size_t)o * k + ky) * k + kx) * cin + c] = v;  // [co][ky][kx][ci]
+          }
+    }
+  }
+  if (h->cfg.lstm) {
+    for (int l = 0; l < 2; l++) {
+      const int nin = l == 0 ? 512 : nh, nout = l == 0 ? nh : nclass;
+      const std::string pr = "rnn." + std::to_string(l) + ".rnn.";
+      const float *wih[2], *whh[2], *bih[2], *bhh[2];
+      for (int d = 0; d < 2; d++) {
+        const std::string sfx = d ? "_reverse" : "";
+        wih[d] = find_tensor(m, pr + "weight_ih_l0" + sfx, {4 * nh, nin}, err);
+        whh[d] = wih[d] ? find_tensor(m, pr + "weight_hh_l0" + sfx, {4 * nh, nh}, err) : nullptr;
+        bih[d] = whh[d] ? find_tensor(m, pr + "bias_ih_l0" + sfx, {4 * nh}, err) : nullptr;
+        bhh[d] = bih[d] ? find_tensor(m, pr + "bias_hh_l0" + sfx, {4 * nh}, err) : nullptr;
+        if (!bhh[d]) return fail(h, CRNN_ERR_ARG, err);
+      }
+      h->h_wih[l].resize((size_t)2 * 4 * nh * nin);
+      h->h_bih[l].resize((size_t)2 * 4 * nh);
+      for (int d = 0; d < 2; d++) {
+        memcpy(h->h_wih[l].data() + (size_t)d * 4 * nh * nin, wih[d], sizeof(float) * 4 * nh * nin);
+        for (int j = 0; j < 4 * nh; j++) h->h_bih[l][(size_t)d * 4 * nh + j] = bih[d][j] + bhh[d][j];
+      }
+      h->h_whhp[l].resize((size_t)2 * 4 * nh * nh);
+      pack_whh(whh[0], whh[1], h->h_whhp[l].data());
+      const std::string pe = "rnn." + std::to_string(l) + ".embedding.";
+      const float* ew = find_tensor(m, pe + "weight", {nout, 2 * nh}, err);
+      const float* eb = ew ? find_tensor(m, pe + "bias", {nout}, err) : nullptr;
+      if (!eb) return fail(h, CRNN_ERR_ARG, err);
+      h->h_emb_w[l].assign(ew, ew + (size_t)nout * 2 * nh);
+      h->h_emb_b[l].assign(eb, eb + nout);
+    }
+  } else {
+    const float* lw = find_tensor(m, "linear.weight", {nclass, 2 * nh}, err);
+    const float* lb = lw ? find_tensor(m, "linear.bias", {nclass}, err) : nullptr;
+    if (!lb) return fail(h, CRNN_ERR_ARG, err);
+    h->h_lin_w.assign(lw, lw + (size_t)nclass * 2 * nh);
+    h->h_lin_b.assign(lb, lb + nclass);
+  }
+  h->loaded = true;
+  return 0;
+}
+
+int crnn_resized_width(const crnn_handle* h, int32_t src_w, int32_t src_h) {
+  if (src_h == 0) return fail(h, CRNN_ERR_ZERO_H, "image height 0 (ZeroDivisionError in resizeNormalize)");
+  if (src_h < 0 || src_w < 0) return fail(h, CRNN_ERR_ARG, "negative image size");
+  return resized_width(src_w, src_h, 32);
+}
+
+int crnn_out_len(int32_t w) { return w < 4 ? 0 : Geo(1, w).T; }
+
+int crnn_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
+                    const int32_t* row_strides, const int32_t* channels, int32_t n, int32_t wp, float* out_host,
+                    int32_t* out_w) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (n <= 0 || !out_host || !out_w) return fail(h, CRNN_ERR_ARG, "bad arguments");
+  int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
+  if (rc) return rc;
+  std::vector<int> sel(n), dw(n);
+  for (int i = 0; i < n; i++) {
+    sel[i] = i;
+    dw[i] = resized_width(widths[i], heights[i], 32);
+    out_w[i] = dw[i];
+    if (dw[i] > wp) return fail(h, CRNN_ERR_ARG, "wp smaller than a resized width");
+  }
+  if ((rc = ensure_device(h, false))) return rc;
+  const size_t bytes = (size_t)n * 32 * wp * sizeof(float);
+  if ((rc = ensure_buf(h, h->arena, bytes))) return rc;
+  if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, wp, (float*)h->arena.p)))
+    return rc;
+  HIPCHK(h, hipMemcpy(out_host, h->arena.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
+                       const int32_t* row_strides, const int32_t* channels, int32_t n, int32_t pad_mode,
+                       int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t,
+                       float* out_logits) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (n <= 0 || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
+  if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
+  int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
+  if (rc) return rc;
+  std::vector<int> sel, dw;
+  int Wp = 0;
+  for (int i = 0; i < n; i++) {
+    const int w = resized_width(widths[i], heights[i], 32);
+    out_len[i] = 0;
+    if (out_t) out_t[i] = 0;
+    if (pad_mode == CRNN_PAD_PER_LINE && w < 8) continue;  // network_torch.py:141-142 -> ''
+    sel.push_back(i);
+    dw.push_back(w);
+    if (w > Wp) Wp = w;
+  }
+  if (sel.empty()) return 0;
+  if (Wp < 4) return fail(h, CRNN_ERR_ARG, "padded width < 4: the conv stack has no output");
+  const Geo g((int)sel.size(), Wp);
+  if (tmax < g.T) return fail(h, CRNN_ERR_ARG, "tmax smaller than the number of timesteps");
+  if ((rc = ensure_device(h))) return rc;
+  Plan p;
+  if ((rc = prepare_plan(h, g, p))) return rc;
+  const size_t nT = (size_t)g.n * g.T;
+  if ((rc = ensure_buf(h, h->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
+  int32_t* d_lab = (int32_t*)h->io.p;
+  int32_t* d_len = d_lab + ((nT + 63) / 64) * 64;
+  if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, Wp, p.x))) return rc;
+  std::vector<int32_t> wv(dw.begin(), dw.end());
+  const bool uniform = pad_mode == CRNN_PAD_REFERENCE;
+  if ((rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len))) return rc;
+  std::vector<int32_t> lab(nT), raw(nT), len(g.n);
+  HIPCHK(h, hipMemcpyAsync(lab.data(), d_lab, nT * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(raw.data(), p.raw, nT * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(len.data(), d_len, (size_t)g.n * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  std::vector<float> lg;
+  if (out_logits) {
+    lg.resize(nT * (size_t)h->cfg.nclass);
+    HIPCHK(h, hipMemcpy(lg.data(), p.logits, lg.size() * 4, hipMemcpyDeviceToHost));
+  }
+  for (int j = 0; j < g.n; j++) {
+    const int i = sel[j];
+    const int Ti = uniform ? g.T : Geo(1, dw[j]).T;
+    out_len[i] = len[j];
+    if (out_t) out_t[i] = Ti;
+    memcpy(out_lab + (size_t)i * tmax, lab.data() + (size_t)j * g.T, sizeof(int32_t) * len[j]);
+    if (out_raw) memcpy(out_raw + (size_t)i * tmax, raw.data() + (size_t)j * g.T, sizeof(int32_t) * Ti);
+    if (out_logits)
+      memcpy(out_logits + (size_t)i * tmax * h->cfg.nclass, lg.data() + (size_t)j * g.T * h->cfg.nclass,
+             sizeof(float) * (size_t)Ti * h->cfg.nclass);
+  }
+  return 0;
+}
+
+int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_t w, const int32_t* widths,
+                        int32_t* d_raw, int32_t* d_lab, int32_t* d_len, int32_t sync) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!d_gray || n <= 0 || w < 8 || !d_lab || !d_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
+  if (widths)
+    for (int i = 0; i < n; i++)
+      if (widths[i] < 8 || widths[i] > w) return fail(h, CRNN_ERR_ARG, "line width outside [8, w]");
+  int rc = ensure_device(h);
+  if (rc) return rc;
+  const Geo g(n, w);
+  Plan p;
+  if ((rc = prepare_plan(h, g, p))) return rc;
+  int32_t* d_w = nullptr;
+  if (widths) {
+    d_w = p.wl + 4 * (size_t)n;
+    HIPCHK(h, hipMemcpyAsync(d_w, widths, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  launch_normalize(d_gray, p.x, d_w, n, w, w, h->stream);
+  if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
+  if (d_raw)
+    HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, h->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const int32_t* widths, int32_t stage,
+                     float* out_host, int64_t out_floats) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!x || n <= 0 || w < 4 || stage < 0 || stage > 10 || !out_host) return fail(h, CRNN_ERR_ARG, "bad arguments");
+  int rc = ensure_device(h);
+  if (rc) return rc;
+  const Geo g(n, w);
+  Plan p;
+  if ((rc = prepare_plan(h, g, p))) return rc;
+  const size_t nT = (size_t)g.n * g.T;
+  if ((rc = ensure_buf(h, h->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
+  int32_t* d_lab = (int32_t*)h->io.p;
+  int32_t* d_len = d_lab + ((nT + 63) / 64) * 64;
+  HIPCHK(h, hipMemcpyAsync(p.x, x, sizeof(float) * (size_t)n * 32 * w, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((size_t)out_floats < h->st_floats[stage]) return fail(h, CRNN_ERR_ARG, "out_host too small for this stage");
+  HIPCHK(h, hipMemcpy(out_host, h->st[stage], h->st_floats[stage] * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int crnn_synchronize(crnn_handle* h) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!h->dev_ready) return 0;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+void* crnn_stream(crnn_handle* h) {
+  if (!h) return nullptr;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (ensure_device(h, false)) return nullptr;
+  return (void*)h->stream;
+}
+
+int crnn_last_timing(crnn_handle* h, float ms[5]) {
+  if (!h || !ms) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!h->ev_valid) return fail(h, CRNN_ERR_STATE, "nothing has run yet");
+  HIPCHK(h, hipEventSynchronize(h->ev[4]));
+  for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+  HIPCHK(h, hipEventElapsedTime(&ms[4], h->ev[0], h->ev[4]));
+  return 0;
+}
+
+const char* crnn_last_error(const crnn_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+void crnn_destroy(crnn_handle* h) {
+  if (!h) return;
+  if (h->dev_ready && h->dev_pid == getpid()) {
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 7; i++) { (void)hipFree(h->d_conv_w[i]); (void)hipFree(h->d_conv_b[i]); }
+    for (int l = 0; l < 2; l++) {
+      (void)hipFree(h->d_wih[l]); (void)hipFree(h->d_bih[l]); (void)hipFree(h->d_whhp[l]);
+      (void)hipFree(h->d_emb_w[l]); (void)hipFree(h->d_emb_b[l]);
+    }
+    (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b);
+    (void)hipFree(h->arena.p); (void)hipFree(h->pre.p); (void)hipFree(h->io.p);
+    for (int i = 0; i < 5; i++) (void)hipEventDestroy(h->ev[i]);
+    (void)hipStreamDestroy(h->stream);
+  }
+  delete h;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Internal launch interface between crnn_api.hip (host side of the C-ABI)
+// and crnn_kernels.hip (gfx950 kernels).  Not part of the public boundary;
+// the public boundary is include/crnn_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crnn {
+
+// Implicit-GEMM convolution / plain GEMM on the f32 MFMA:
+//   C[m][n] = act( sum_k A_im2col[m][k] * Wt[n][k] + bias[n] ),  m = (b, y, x) of the OUTPUT
+// A is NHWC [B,Hin,Win,Cin]; K = ks*ks*Cin ordered (ky,kx,ci); a plain GEMM is
+// the 1x1 case with Hin=Win=Hout=Wout=1, Cin=K.
+struct ConvGemm {
+  const float* A;
+  const float* Wt;    // [N][K]
+  const float* bias;  // [N]
+  float* C;           // [M][ldc]
+  const int32_t* wvalid;  // per-sample valid output width (x >= wvalid[b] -> 0) or nullptr
+  int M, N, K, ldc;
+  int Hin, Win, Cin, Hout, Wout, ks, pad;
+  int act;            // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
+};
+
+void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
+
+// conv0 (1->64, 3x3, pad 1) + ReLU + MaxPool 2x2/2, direct (K = 9, HBM-bound).
+// in f32 [B,32,W]; out NHWC [B,16,W/2,64]; w1valid: per-sample valid pooled width or nullptr.
+void launch_conv0_pool(const float* in, const float* w9x64, const float* bias, float* out,
+                       const int32_t* w1valid, int B, int W, int act, hipStream_t s);
+
+// NHWC max pools.  pool_2x2s2: [B,H,W,C] -> [B,H/2,W/2,C].
+// pool_2x2s21p01: kernel (2,2) stride (2,1) pad (0,1): [B,H,W,C] -> [B,H/2,W+1,C].
+void launch_pool_2x2s2(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+void launch_pool_2x2s21p01(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+
+// LSTM recurrence, both directions.  xp [B*T][2*4*nh] (input projection with
+// b_ih+b_hh already added; col = dir*4nh + gate*nh + unit), whh_packed as
+// produced by pack_whh(), rec [B*T][2*nh] (col = dir*nh + unit).  nh == 256.
+void launch_lstm_rec(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen,
+                     int B, int T, hipStream_t s);
+// host-side repack of W_hh [2][1024][256] into the per-lane fragment order the kernel streams.
+void pack_whh(const float* whh_fwd, const float* whh_rev, float* packed /* 2*1024*256 */);
+
+// row-wise argmax over nclass (ties -> lowest index); logits [M][ld] -> idx [M]
+void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld, hipStream_t s);
+
+// greedy CTC collapse (util.py:16-22): idx [B][T] -> out [B][T] alphabet positions (class-1), len [B]
+void launch_ctc(const int32_t* idx, const int32_t* tlen, int32_t* out, int32_t* len, int B, int T,
+                hipStream_t s);
+
+// preprocessing ------------------------------------------------------------
+// 256-entry table (x/255-0.5)/0.5 computed on the host in float64 like util.py:12
+void upload_norm_lut(const float* lut256, hipStream_t s);
+// u8 gray [B,32,W] (already at height 32, width W) -> normalised f32 [B,32,Wp], zero beyond w[b]
+void launch_normalize(const uint8_t* gray, float* out, const int32_t* w, int B, int W, int Wp,
+                      hipStream_t s);
+
+struct ResizeJob {        // one source image (device resident)
+  int64_t src_off;        // byte offset into the packed source buffer
+  int32_t sh, sw, stride, ch;   // source height/width/row stride in bytes/channels (1 gray, 3 BGR)
+  int32_t dw;             // resized width (util.py:7-9)
+  int32_t ksh, ksv;       // taps per output column / row (a pass over an unchanged dimension
+                          // has coefficients {1,0}: identical to Pillow skipping it)
+  int32_t ybox_first, th; // first source row the vertical pass needs, rows of the temp image
+  int64_t tmp_off;        // byte offset of this image's temp (horizontal pass output) [th][dw]
+  int64_t coef_off;       // int32 offset of this image's coefficient block:
+                          //   bounds_h[2*dw], kk_h[dw*ksh], bounds_v[64], kk_v[32*ksv]
+};
+// gray + Pillow BILINEAR horizontal pass -> tmp u8
+void launch_resize_h(const uint8_t* src, const ResizeJob* jobs, const int32_t* coef, uint8_t* tmp,
+                     int n, int max_th, int max_dw, hipStream_t s);
+// vertical pass + normalise -> f32 [n,32,Wp] (zero beyond dw)
+void launch_resize_v(const uint8_t* src, const ResizeJob* jobs, const int32_t* coef, const uint8_t* tmp,
+                     float* out, int n, int Wp, hipStream_t s);
+
+}  // namespace crnn

@@ -1,0 +1,553 @@
+// gfx950 (MI355X / CDNA4) kernels of the CRNN text-line recogniser.
+//
+// Replaces, on the GPU, the torch CPU operators the reference runs in
+// crnn/network_torch.py:44-108 (conv/BN/ReLU/pool backbone, two BiLSTMs,
+// classifier), :144 (argmax) and crnn/util.py:6-22 (resize/normalise, greedy
+// CTC collapse).  fp32 throughout: matrix work goes through the exact-f32
+// MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32, a k-ordered fmaf
+// chain), byte/integer work is plain coalesced vector code.
+#include "crnn_kernels.h"
+
+namespace crnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// Implicit-GEMM convolution / GEMM.  128x128 output tile per 256-thread block,
+// BK = 32, 4 waves as 2(M) x 2(N), each wave 2x2 MFMA tiles of 32x32.
+// LDS tiles are [row][k] with rows padded to 36 floats so that the 16-lane
+// groups of a ds_read_b128 hit 16 distinct 4-bank slots (conflict free).
+// One k-group = 8 consecutive k: lane half h holds k = 8g+4h .. 8g+4h+3 of its
+// row as one float4, and MFMA j of the group consumes element j of both
+// operands (k pair {8g+j, 8g+4+j}); A and B use the same permutation, so the
+// sum over k is complete.
+// ---------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
+
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemm p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int bm = blockIdx.x / ntn, bn = blockIdx.x - bm * ntn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const int lrow = tid >> 3;
+  const int lk = (tid & 7) * 4;
+  const int hw = p.Hout * p.Wout;
+
+  int ay[4], ax[4];
+  long abase[4];
+  bool aval[4], bval[4];
+  const float* bptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int m = m0 + lrow + 32 * i;
+    aval[i] = m < p.M;
+    int mm = aval[i] ? m : 0;
+    int b = mm / hw, r = mm - b * hw;
+    int y = r / p.Wout, x = r - y * p.Wout;
+    abase[i] = (long)b * p.Hin * p.Win;
+    ay[i] = y - p.pad;
+    ax[i] = x - p.pad;
+    int n = n0 + lrow + 32 * i;
+    bval[i] = n < p.N;
+    bptr[i] = p.Wt + (long)(bval[i] ? n : 0) * p.K + lk;
+  }
+  const int nk = p.K / BK;
+  f32x4 ra[4], rb[4];
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    const int tap = k0 / p.Cin;
+    const int ci = k0 - tap * p.Cin + lk;
+    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int yy = ay[i] + ky, xx = ax[i] + kx;
+      bool ok = aval[i] && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ra[i] = ok ? *(const f32x4*)(p.A + ((abase[i] + (long)yy * p.Win + xx) * p.Cin + ci)) : z;
+      rb[i] = bval[i] ? *(const f32x4*)(bptr[i] + k0) : z;
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* sa = smem + buf * (BM + BN) * LDT;
+    float* sb = sa + BM * LDT;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      *(f32x4*)(sa + (lrow + 32 * i) * LDT + lk) = ra[i];
+      *(f32x4*)(sb + (lrow + 32 * i) * LDT + lk) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const float* a = smem + cur * (BM + BN) * LDT + (wm * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
+    const float* b = smem + cur * (BM + BN) * LDT + BM * LDT + (wn * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
+#pragma unroll
+    for (int kg = 0; kg < 4; kg++) {
+      f32x4 a0 = *(const f32x4*)(a + kg * 8);
+      f32x4 a1 = *(const f32x4*)(a + 32 * LDT + kg * 8);
+      f32x4 b0 = *(const f32x4*)(b + kg * 8);
+      f32x4 b1 = *(const f32x4*)(b + 32 * LDT + kg * 8);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: bias + activation + per-sample width mask.  C/D map of the 32x32
+  // MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
+    const bool nok = n < p.N;
+    const float bias = nok ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[mt][nt][r] + bias;
+        if (p.act == 1) v = v > 0.f ? v : 0.f;
+        else if (p.act == 2) v = v > 0.f ? v : 0.2f * v;
+        if (row < p.M) {
+          if (p.wvalid) {
+            int b = row / hw, rr = row - b * hw;
+            int x = rr % p.Wout;
+            if (x >= p.wvalid[b]) v = 0.f;
+          }
+          if (nok) p.C[(long)row * p.ldc + n] = v;
+        }
+      }
+    }
+  }
+}
+
+void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL(conv_gemm_kernel, dim3(ntm * ntn), dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
+// conv0 + ReLU + pool0, direct.  16 pooled pixels x 16 channel groups (4 ch)
+// per 256-thread block; each thread keeps its 9x4 weights in registers, reads a
+// 4x4 input patch and writes one float4 of the NHWC output (256 B per pixel).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv0_pool_kernel(const float* __restrict__ in,
+                                                         const float* __restrict__ w9x64,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ out,
+                                                         const int32_t* __restrict__ w1valid, int B,
+                                                         int W, int act) {
+  const int W1 = W >> 1;
+  const int cg = threadIdx.x & 15;
+  const long npix = (long)B * 16 * W1;
+  f32x4 wr[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++) wr[t] = *(const f32x4*)(w9x64 + t * 64 + cg * 4);
+  const f32x4 bs = *(const f32x4*)(bias + cg * 4);
+  for (long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long)gridDim.x * 16) {
+    const int b = (int)(pix / (16 * W1));
+    const int r = (int)(pix - (long)b * 16 * W1);
+    const int y1 = r / W1, x1 = r - y1 * W1;
+    const float* ip = in + (long)b * 32 * W;
+    float patch[4][4];
+#pragma unroll
+    for (int dy = 0; dy < 4; dy++) {
+      const int yy = 2 * y1 - 1 + dy;
+#pragma unroll
+      for (int dx = 0; dx < 4; dx++) {
+        const int xx = 2 * x1 - 1 + dx;
+        const bool ok = (unsigned)yy < 32u && (unsigned)xx < (unsigned)W;
+        patch[dy][dx] = ok ? ip[yy * W + xx] : 0.f;
+      }
+    }
+    f32x4 best;
+#pragma unroll
+    for (int py = 0; py < 2; py++)
+#pragma unroll
+      for (int px = 0; px < 2; px++) {
+        f32x4 a = bs;
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) {
+            const float v = patch[py + ky][px + kx];
+            a += wr[ky * 3 + kx] * v;
+          }
+        if (py == 0 && px == 0) best = a;
+        else {
+#pragma unroll
+          for (int c = 0; c < 4; c++) best[c] = a[c] > best[c] ? a[c] : best[c];
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      float v = best[c];
+      if (act == 1) v = v > 0.f ? v : 0.f;
+      else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+      best[c] = v;
+    }
+    if (w1valid && x1 >= w1valid[b]) best = f32x4{0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)(out + pix * 64 + cg * 4) = best;
+  }
+}
+
+void launch_conv0_pool(const float* in, const float* w9x64, const float* bias, float* out,
+                       const int32_t* w1valid, int B, int W, int act, hipStream_t s) {
+  long npix = (long)B * 16 * (W >> 1);
+  long blocks = (npix + 15) / 16;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(conv0_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, w9x64, bias, out,
+                     w1valid, B, W, act);
+}
+
+// ---------------------------------------------------------------------------
+// NHWC max pools (float4 over channels)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
+  f32x4 r;
+#pragma unroll
+  for (int c = 0; c < 4; c++) r[c] = a[c] > b[c] ? a[c] : b[c];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void pool_2x2s2_kernel(const float* __restrict__ in,
+                                                         float* __restrict__ out, int B, int H, int W,
+                                                         int C) {
+  const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long pix = i / C4;
+    const int x = (int)(pix % Wo);
+    pix /= Wo;
+    const int y = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    const float* p = in + (((long)b * H + 2 * y) * W + 2 * x) * C + c4 * 4;
+    f32x4 v = max4(max4(*(const f32x4*)p, *(const f32x4*)(p + C)),
+                   max4(*(const f32x4*)(p + (long)W * C), *(const f32x4*)(p + (long)W * C + C)));
+    *(f32x4*)(out + i * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_2x2s21p01_kernel(const float* __restrict__ in,
+                                                             float* __restrict__ out, int B, int H,
+                                                             int W, int C) {
+  const int Ho = H >> 1, Wo = W + 1, C4 = C >> 2;
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long pix = i / C4;
+    const int x = (int)(pix % Wo);
+    pix /= Wo;
+    const int y = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    const float* r0 = in + (((long)b * H + 2 * y) * W) * C + c4 * 4;
+    const float* r1 = r0 + (long)W * C;
+    f32x4 v;
+    if (x < W) {
+      v = max4(*(const f32x4*)(r0 + (long)x * C), *(const f32x4*)(r1 + (long)x * C));
+      if (x > 0) v = max4(v, max4(*(const f32x4*)(r0 + (long)(x - 1) * C), *(const f32x4*)(r1 + (long)(x - 1) * C)));
+    } else {
+      v = max4(*(const f32x4*)(r0 + (long)(x - 1) * C), *(const f32x4*)(r1 + (long)(x - 1) * C));
+    }
+    *(f32x4*)(out + i * 4) = v;
+  }
+}
+
+static unsigned ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+void launch_pool_2x2s2(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+  long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(pool_2x2s2_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, in, out, B, H, W, C);
+}
+void launch_pool_2x2s21p01(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+  long total = (long)B * (H / 2) * (W + 1) * (C / 4);
+  hipLaunchKernelGGL(pool_2x2s21p01_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, in, out, B, H, W, C);
+}
+
+// ---------------------------------------------------------------------------
+// LSTM recurrence.  One 256-thread workgroup per (direction, 16 samples); no
+// cross-workgroup communication.  Per step gates^T[1024 x 16] = W_hh[1024x256]
+// . h^T[256x16] on v_mfma_f32_16x16x4_f32: wave w owns hidden units
+// [64w, 64w+64) of all four gates (16 MFMA row tiles), so i,f,g,o of one
+// (unit, sample) land in the same lane and the cell update needs no exchange.
+// W_hh streams from L2 in a pre-packed per-lane fragment order (1 KiB per
+// wave-instruction); h lives in LDS (double buffered), c in registers.
+// ---------------------------------------------------------------------------
+constexpr int LB = 16, HS = 260;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_rec_kernel(const float* __restrict__ xp,
+                                                       const float* __restrict__ whhp,
+                                                       float* __restrict__ rec,
+                                                       const int32_t* __restrict__ tlen, int B, int T) {
+  __shared__ __attribute__((aligned(16))) float hs[2 * LB * HS];
+  const int dir = blockIdx.y, b0 = blockIdx.x * LB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
+  const int b = b0 + bl;
+  const int Ti = (b < B) ? (tlen ? tlen[b] : T) : 0;
+  int Tmax = 0;
+  for (int j = 0; j < LB; j++) {
+    int bb = b0 + j;
+    int tj = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
+    Tmax = tj > Tmax ? tj : Tmax;
+  }
+  for (int i = tid; i < 2 * LB * HS; i += 256) hs[i] = 0.f;
+  float c[4][4], h[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { c[u][r] = 0.f; h[u][r] = 0.f; }
+  const f32x4* wp = (const f32x4*)whhp + ((size_t)(dir * 4 + wave) * 16 * 16) * 64 + lane;
+  __syncthreads();
+  int cur = 0;
+  for (int s = 0; s < Tmax; s++) {
+    const bool active = s < Ti;
+    const int t = active ? (dir ? (Ti - 1 - s) : s) : 0;
+    const size_t rowi = (size_t)(b < B ? b : 0) * T + t;
+    const float* xrow = xp + rowi * 2048 + dir * 1024 + wave * 64 + q * 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        acc[g][u] = active ? *(const f32x4*)(xrow + g * 256 + u * 16) : z;
+      }
+    const float* hrow = hs + cur * LB * HS + bl * HS + 4 * q;
+#pragma unroll 2
+    for (int kg = 0; kg < 16; kg++) {
+      const f32x4 hv = *(const f32x4*)(hrow + kg * 16);
+#pragma unroll
+      for (int tile = 0; tile < 16; tile++) {
+        const f32x4 av = wp[(size_t)(tile * 16 + kg) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[tile >> 2][tile & 3] =
+              __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], hv[j], acc[tile >> 2][tile & 3], 0, 0, 0);
+      }
+    }
+    float* hn = hs + (cur ^ 1) * LB * HS + bl * HS + wave * 64 + q * 4;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      f32x4 hv4;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (active) {
+          const float ig = sigmoidf_(acc[0][u][r]);
+          const float fg = sigmoidf_(acc[1][u][r]);
+          const float gg = tanhf(acc[2][u][r]);
+          const float og = sigmoidf_(acc[3][u][r]);
+          c[u][r] = fg * c[u][r] + ig * gg;
+          h[u][r] = og * tanhf(c[u][r]);
+        }
+        hv4[r] = h[u][r];
+      }
+      *(f32x4*)(hn + u * 16) = hv4;
+      if (active) *(f32x4*)(rec + rowi * 512 + dir * 256 + wave * 64 + u * 16 + q * 4) = hv4;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+void launch_lstm_rec(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,
+                     int T, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_rec_kernel, dim3((B + LB - 1) / LB, 2), dim3(256), 0, s, xp, whh_packed, rec,
+                     tlen, B, T);
+}
+
+void pack_whh(const float* whh_fwd, const float* whh_rev, float* packed) {
+  for (int dir = 0; dir < 2; dir++) {
+    const float* w = dir ? whh_rev : whh_fwd;
+    for (int wave = 0; wave < 4; wave++)
+      for (int tile = 0; tile < 16; tile++)
+        for (int kg = 0; kg < 16; kg++)
+          for (int lane = 0; lane < 64; lane++) {
+            const int g = tile >> 2, u = tile & 3, q = lane >> 4, bl = lane & 15;
+            const int row = g * 256 + wave * 64 + u * 16 + bl;
+            const int k = kg * 16 + 4 * q;
+            float* dst = packed + ((((size_t)(dir * 4 + wave) * 16 + tile) * 16 + kg) * 64 + lane) * 4;
+            for (int j = 0; j < 4; j++) dst[j] = w[(size_t)row * 256 + k + j];
+          }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// argmax over classes, one wave per row; ties -> lowest index (torch CPU max)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits,
+                                                     int32_t* __restrict__ idx, int M, int nclass,
+                                                     int ld) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* p = logits + (long)row * ld;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int k = lane; k < nclass; k += 64) {
+    const float v = p[k];
+    if (v > bv || bi == 0x7fffffff) { bv = v; bi = k; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) idx[row] = bi;
+}
+
+void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, idx, M, nclass, ld);
+}
+
+// ---------------------------------------------------------------------------
+// greedy CTC collapse, one thread per line
+// ---------------------------------------------------------------------------
+__global__ void ctc_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ tlen,
+                           int32_t* __restrict__ out, int32_t* __restrict__ len, int B, int T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int Ti = tlen ? tlen[b] : T;
+  const int32_t* p = idx + (long)b * T;
+  int32_t* o = out + (long)b * T;
+  int n = 0, prev = -1;
+  for (int i = 0; i < Ti; i++) {
+    const int k = p[i];
+    if (k != 0 && k != prev) o[n++] = k - 1;
+    prev = k;
+  }
+  len[b] = n;
+}
+
+void launch_ctc(const int32_t* idx, const int32_t* tlen, int32_t* out, int32_t* len, int B, int T,
+                hipStream_t s) {
+  hipLaunchKernelGGL(ctc_kernel, dim3((B + 63) / 64), dim3(64), 0, s, idx, tlen, out, len, B, T);
+}
+
+// ---------------------------------------------------------------------------
+// preprocessing
+// ---------------------------------------------------------------------------
+__constant__ float c_norm_lut[256];
+
+__global__ __launch_bounds__(256) void normalize_kernel(const uint8_t* __restrict__ gray,
+                                                        float* __restrict__ out,
+                                                        const int32_t* __restrict__ w, int B, int W,
+                                                        int Wp) {
+  const long total = (long)B * 32 * Wp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const long row = i / Wp;  // b*32 + y
+    const int b = (int)(row >> 5);
+    const int wb = w ? w[b] : W;
+    out[i] = (x < wb && x < W) ? c_norm_lut[gray[row * W + x]] : 0.f;
+  }
+}
+
+void launch_normalize(const uint8_t* gray, float* out, const int32_t* w, int B, int W, int Wp,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(normalize_kernel, dim3(ew_blocks((long)B * 32 * Wp)), dim3(256), 0, s, gray, out, w,
+                     B, W, Wp);
+}
+
+constexpr int PREC = 22;
+
+__device__ __forceinline__ int src_gray(const uint8_t* row, int x, int ch) {
+  if (ch == 1) return row[x];
+  const int b = row[3 * x], g = row[3 * x + 1], r = row[3 * x + 2];
+  return (19595 * r + 38470 * g + 7471 * b + 0x8000) >> 16;
+}
+
+__device__ __forceinline__ int clip8(int v) {
+  v >>= PREC;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict__ src,
+                                                       const ResizeJob* __restrict__ jobs,
+                                                       const int32_t* __restrict__ coef,
+                                                       uint8_t* __restrict__ tmp) {
+  const ResizeJob j = jobs[blockIdx.z];
+  const int yy = blockIdx.y;
+  const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (yy >= j.th || xx >= j.dw) return;
+  const int32_t* bh = coef + j.coef_off;
+  const int32_t* kh = bh + 2 * j.dw;
+  const int xmin = bh[2 * xx], xmax = bh[2 * xx + 1];
+  const int32_t* k = kh + (long)xx * j.ksh;
+  const uint8_t* row = src + j.src_off + (long)(yy + j.ybox_first) * j.stride;
+  int ss = 1 << (PREC - 1);
+  for (int x = 0; x < xmax; x++) ss += src_gray(row, x + xmin, j.ch) * k[x];
+  tmp[j.tmp_off + (long)yy * j.dw + xx] = (uint8_t)clip8(ss);
+}
+
+__global__ __launch_bounds__(256) void resize_v_kernel(const ResizeJob* __restrict__ jobs,
+                                                       const int32_t* __restrict__ coef,
+                                                       const uint8_t* __restrict__ tmp,
+                                                       float* __restrict__ out, int Wp) {
+  const ResizeJob j = jobs[blockIdx.z];
+  const int yy = blockIdx.y;
+  const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xx >= Wp) return;
+  float v = 0.f;
+  if (xx < j.dw) {
+    const int32_t* bv = coef + j.coef_off + 2 * j.dw + (long)j.dw * j.ksh;
+    const int32_t* kv = bv + 64;
+    const int ymin = bv[2 * yy], ymax = bv[2 * yy + 1];
+    const int32_t* k = kv + yy * j.ksv;
+    const uint8_t* col = tmp + j.tmp_off + xx;
+    int ss = 1 << (PREC - 1);
+    for (int y = 0; y < ymax; y++) ss += (int)col[(long)(y + ymin) * j.dw] * k[y];
+    v = c_norm_lut[clip8(ss)];
+  }
+  out[((long)blockIdx.z * 32 + yy) * Wp + xx] = v;
+}
+
+void launch_resize_h(const uint8_t* src, const ResizeJob* jobs, const int32_t* coef, uint8_t* tmp, int n,
+                     int max_th, int max_dw, hipStream_t s) {
+  hipLaunchKernelGGL(resize_h_kernel, dim3((max_dw + 255) / 256, max_th, n), dim3(256), 0, s, src, jobs,
+                     coef, tmp);
+}
+void launch_resize_v(const uint8_t* /*src*/, const ResizeJob* jobs, const int32_t* coef,
+                     const uint8_t* tmp, float* out, int n, int Wp, hipStream_t s) {
+  hipLaunchKernelGGL(resize_v_kernel, dim3((Wp + 255) / 256, 32, n), dim3(256), 0, s, jobs, coef, tmp,
+                     out, Wp);
+}
+
+void upload_norm_lut(const float* lut256, hipStream_t s) {
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(c_norm_lut), lut256, 256 * sizeof(float), 0,
+                               hipMemcpyHostToDevice, s);
+}
+
+}  // namespace crnn

@@ -58,6 +58,7 @@ ORACLE_API void oracle_bgr_to_gray(const uint8_t *bgr, int h, int w, long row_st
 }
 
 /* util.py:7-9 -- scale = H*1.0/imgH; w = int(W/scale) */
+__attribute__((optimize("fp-contract=off")))
 ORACLE_API int oracle_resized_width(int src_w, int src_h, int img_h) {
   double scale = (double)src_h * 1.0 / (double)img_h;
   double w = (double)src_w / scale;
@@ -66,6 +67,7 @@ ORACLE_API int oracle_resized_width(int src_w, int src_h, int img_h) {
 
 #define PRECISION_BITS (32 - 8 - 2)
 
+__attribute__((optimize("fp-contract=off")))
 static double bilinear_filter(double x) {
   if (x < 0.0) x = -x;
   if (x < 1.0) return 1.0 - x;
@@ -75,6 +77,8 @@ static double bilinear_filter(double x) {
 /* Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc (BILINEAR,
  * support 1.0, box = whole image).  Returns ksize; allocates bounds[2*out]
  * and kk[out*ksize] (22-bit fixed point). */
+/* no FMA contraction: Pillow's build evaluates these as separate double operations */
+__attribute__((optimize("fp-contract=off")))
 ORACLE_API int oracle_resample_coeffs(int in_size, int out_size, int **bounds_out, int32_t **kk_out) {
   double support, scale, filterscale, center, ww, ss;
   int xx, x, ksize, xmin, xmax;
@@ -184,6 +188,7 @@ ORACLE_API int oracle_resize_bilinear_u8(const uint8_t *src, int sw, int sh, lon
 
 /* util.py:12 -- (x/255.0-0.5)/0.5 in float64, cast to float32 by the caller
  * (network_torch.py:132). */
+__attribute__((optimize("fp-contract=off")))
 ORACLE_API void oracle_normalize_u8(const uint8_t *src, long n, float *dst) {
   for (long i = 0; i < n; i++) dst[i] = (float)(((double)src[i] / 255.0 - 0.5) / 0.5);
 }

@@ -1,0 +1,165 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the
+golden fixtures captured from the reference.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from ocr_amd.crnn import keys
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3   # north star: fp32 logits within 1e-3 of the reference torch CPU path
+
+
+@pytest.fixture(scope="module")
+def hip_zh(synth_zh):
+    from ocr_amd.crnn.network_hip import CRNN
+    m = CRNN(32, 1, 5530, 256, leakyRelu=False, lstmFlag=True, GPU=True, alphabet=keys.alphabetChinese)
+    m.load_state_dict(synth_zh)
+    return m
+
+
+@pytest.fixture(scope="module")
+def hip_en(synth_en):
+    from ocr_amd.crnn.network_hip import CRNN
+    m = CRNN(32, 1, 65, 256, leakyRelu=False, lstmFlag=True, GPU=True, alphabet=keys.alphabetEnglish)
+    m.load_state_dict(synth_en)
+    return m
+
+
+def nchw(a):
+    return np.transpose(a, (0, 3, 1, 2))
+
+
+def test_preprocess_bit_exact(golden, hip_zh):
+    """gray + Pillow BILINEAR + normalise: integer work, must be bit-exact."""
+    from oracle import oracle as O
+    G, M = golden
+    imgs, want = [], []
+    for it in M["invoice"]:
+        n = it["name"]
+        imgs.append(G["inv/%s/bgr" % n])
+        want.append(((G["inv/%s/resized" % n] / 255.0 - 0.5) / 0.5).astype(np.float32))
+    for tag in ("upscale", "downscale", "w8", "narrow"):
+        imgs.append(G["edge/%s/gray" % tag])
+        want.append(O.resize_normalize(G["edge/%s/gray" % tag]))
+    got = hip_zh.preprocess(imgs)
+    for g, w, im in zip(got, want, imgs):
+        assert g.shape == w.shape, (g.shape, w.shape, im.shape)
+        assert np.array_equal(g, w)
+    # a strided view into a "page" (detectors pass slices: vat_detect.py:318)
+    page = G["inv/title/bgr"]
+    crop = page[5:60, 12:300]
+    g = hip_zh.preprocess([crop])[0]
+    assert np.array_equal(g, O.resize_normalize(O.bgr_to_gray(crop)))
+
+
+@pytest.mark.parametrize("shape", [(7, 50), (32, 280), (100, 33), (61, 999), (33, 64), (300, 900), (31, 31)])
+def test_preprocess_random_sizes(shape, hip_zh):
+    from oracle import oracle as O
+    rs = np.random.RandomState(shape[0] * 1000 + shape[1])
+    a = rs.randint(0, 256, size=shape).astype(np.uint8)
+    assert np.array_equal(hip_zh.preprocess([a])[0], O.resize_normalize(a))
+    c = rs.randint(0, 256, size=shape + (3,)).astype(np.uint8)
+    assert np.array_equal(hip_zh.preprocess([c])[0], O.resize_normalize(O.bgr_to_gray(c)))
+
+
+def test_stages_against_oracle(golden, hip_zh, oracle_zh):
+    """Every stage of the network, layer by layer, on two lines of different content."""
+    from oracle import oracle as O
+    G, _ = golden
+    x = np.stack([O.resize_normalize(G["syn280/noise/gray"][0]), O.resize_normalize(G["syn280/text/gray"][0])])
+    logits, taps = oracle_zh.forward(x, stages=True)
+    tol = [1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 2e-4, 1e-3, 2e-4, 5e-4]
+    for st in range(7):
+        got = hip_zh.debug_stage(x, st)
+        got = nchw(got) if st < 6 else np.transpose(got, (0, 2, 1))[:, :, None, :]
+        assert got.shape == taps[st].shape, st
+        assert np.abs(got - taps[st]).max() < tol[st], "stage %d" % st
+    for st in (8, 7, 9):
+        got = np.transpose(hip_zh.debug_stage(x, st), (1, 0, 2))
+        assert np.abs(got - taps[st]).max() < tol[st], "stage %d" % st
+    got = np.transpose(hip_zh.debug_stage(x, 10), (1, 0, 2))
+    assert np.abs(got - logits).max() < LOGIT_TOL
+
+
+def test_invoice_crops_match_reference(golden, hip_zh, hip_en):
+    """Config 1: the 17 invoice crops, one at a time through CRNN.ocr (BGR in, text out)."""
+    G, M = golden
+    for it in M["invoice"]:
+        n = it["name"]
+        bgr = G["inv/%s/bgr" % n]
+        assert hip_zh.ocr(bgr) == it["zh"], n
+        assert hip_en.ocr(bgr) == it["en"], n
+        raw, tt, logits, _, _ = hip_zh.forward_logits([bgr])
+        assert tt[0] == it["T"]
+        assert np.array_equal(raw[0, :tt[0]], G["inv/%s/zh_idx" % n]), n
+        assert np.abs(logits[0, :tt[0]].max(1) - G["inv/%s/zh_toplogit" % n]).max() < LOGIT_TOL
+        raw, tt, logits, _, _ = hip_en.forward_logits([bgr])
+        assert np.abs(logits[0, :tt[0]] - G["inv/%s/en_logits" % n]).max() < LOGIT_TOL, n
+    raw, tt, logits, _, _ = hip_zh.forward_logits([G["inv/invoice_number/bgr"]])
+    assert np.abs(logits[0, :tt[0]] - G["inv/invoice_number/zh_logits"]).max() < LOGIT_TOL
+
+
+def test_predict_pil(golden, hip_zh):
+    from PIL import Image
+    G, M = golden
+    it = M["invoice"][0]
+    img = Image.fromarray(G["inv/%s/gray" % it["name"]], mode="L")
+    assert hip_zh.predict(img) == it["zh"]
+    assert hip_zh.predict(Image.fromarray(G["edge/narrow/gray"], mode="L")) == "" == M["edge_narrow"]
+    for tag in ("upscale", "downscale", "w8"):
+        assert hip_zh.predict(Image.fromarray(G["edge/%s/gray" % tag], mode="L")) == M["edge_%s" % tag], tag
+    with pytest.raises(ValueError):
+        hip_zh.predict(Image.fromarray(np.zeros((100, 2), np.uint8), mode="L"))  # resized width 0
+    with pytest.raises(ValueError):
+        hip_zh.predict(Image.fromarray(np.zeros((10, 10, 3), np.uint8)))  # not mode 'L'
+    with pytest.raises(ValueError):
+        hip_zh.ocr(np.zeros((0, 0, 3), np.uint8))
+
+
+def test_batched_lines_equal_single_predict(golden, hip_zh):
+    """Mixed widths in ONE padded device batch decode exactly as each line alone (per-line masks)."""
+    G, M = golden
+    imgs = [G["inv/%s/bgr" % it["name"]] for it in M["invoice"]]
+    want = [it["zh"] for it in M["invoice"]]
+    imgs += [G["edge/narrow/gray"], G["edge/w8/gray"], G["edge/upscale/gray"]]
+    want += [M["edge_narrow"], M["edge_w8"], M["edge_upscale"]]
+    # one bucket with everything (worst padding), then the bucketed default
+    got = hip_zh.predict_lines(imgs, max_batch=64, width_spread=1e9)
+    assert got == want
+    assert hip_zh.predict_lines(imgs) == want
+    raw, tt, _, _, _ = hip_zh.forward_logits(imgs[:17])
+    for i, it in enumerate(M["invoice"]):
+        assert np.array_equal(raw[i, :tt[i]], G["inv/%s/zh_idx" % it["name"]]), it["name"]
+
+
+def test_predict_batch_reference_semantics(golden, hip_zh, hip_en):
+    """CRNN.predict_batch (network_torch.py:157-200): zero right padding, all padded timesteps decoded."""
+    from PIL import Image
+    G, M = golden
+    pb = M["predict_batch"]
+    boxes = [{"img": Image.fromarray(G["inv/%s/gray" % n], mode="L")} for n in pb["names"]]
+    out = hip_zh.predict_batch(boxes, batch_size=pb["batch_size"])
+    assert out is boxes and [b["text"] for b in out] == pb["zh"]
+    pb = M["predict_batch_en"]
+    boxes = [{"img": Image.fromarray(G["inv/%s/gray" % n], mode="L")} for n in pb["names"]]
+    assert [b["text"] for b in hip_en.predict_batch(boxes, batch_size=pb["batch_size"])] == pb["en"]
+    boxes = [{"img": Image.fromarray(G["inv/%s/gray" % n], mode="L")} for n in pb["names"]]
+    assert [b["text"] for b in hip_en.predict_job(boxes)] == [
+        it["en"] for n in pb["names"] for it in M["invoice"] if it["name"] == n]
+
+
+def test_synthetic_280_and_variable_width(golden, hip_zh, hip_en):
+    G, M = golden
+    for tag in ("noise", "text"):
+        lines = list(G["syn280/%s/gray" % tag])
+        raw, tt, _, lab, ln = hip_zh.forward_logits(lines)
+        assert (tt == 71).all()
+        assert np.array_equal(raw[:, :71], G["syn280/%s/zh_idx" % tag]), tag
+        assert hip_zh.predict_lines(lines) == M["syn280_%s" % tag]
+    lines = [G["var/%d/gray" % w] for w in M["var_widths"]]
+    assert hip_en.predict_lines(lines) == M["var_en"]
+    raw, tt, logits, _, _ = hip_en.forward_logits(lines)
+    for i, w in enumerate(M["var_widths"]):
+        assert tt[i] == w // 4 + 1
+        assert np.abs(logits[i, :tt[i]] - G["var/%d/en_logits" % w]).max() < LOGIT_TOL, w
