@@ -131,6 +131,16 @@ CRNN_API void* crnn_stream(crnn_handle* h);
  * [3] argmax+ctc, [4] total.  Valid after crnn_synchronize. */
 CRNN_API int crnn_last_timing(crnn_handle* h, float ms[5]);
 
+/* Per-launch profiling of crnn_forward_device: when on, a HIP event is recorded on the handle's
+ * stream after every kernel launch.  crnn_last_kernel_times returns, for the most recent
+ * crnn_forward_device, up to `cap` launches in order: a static name, the time between the
+ * events that bracket the launch (ms), its algorithmic FLOPs (2*MACs) and algorithmic bytes
+ * (compulsory reads + writes).  Returns the number of launches written.  Measurement aid for
+ * bench.py's roofline line; no reference counterpart. */
+CRNN_API int crnn_set_profiling(crnn_handle* h, int32_t on);
+CRNN_API int crnn_last_kernel_times(crnn_handle* h, int32_t cap, const char** names, float* ms,
+                                    double* flops, double* bytes);
+
 /* Message of the last failing call on this handle (never NULL). */
 CRNN_API const char* crnn_last_error(const crnn_handle* h);
 

@@ -17,7 +17,7 @@ PAD_PER_LINE, PAD_REFERENCE = 0, 1
 
 SYMBOLS = ["crnn_create", "crnn_load_weights", "crnn_resized_width", "crnn_out_len", "crnn_preprocess",
            "crnn_predict_batch", "crnn_forward_device", "crnn_debug_stage", "crnn_synchronize", "crnn_stream",
-           "crnn_last_timing", "crnn_last_error", "crnn_destroy"]
+           "crnn_last_timing", "crnn_set_profiling", "crnn_last_kernel_times", "crnn_last_error", "crnn_destroy"]
 
 
 class Config(C.Structure):
@@ -64,6 +64,11 @@ def lib():
     L.crnn_stream.argtypes = [vp]
     L.crnn_last_timing.restype = C.c_int
     L.crnn_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
+    L.crnn_set_profiling.restype = C.c_int
+    L.crnn_set_profiling.argtypes = [vp, i32]
+    L.crnn_last_kernel_times.restype = C.c_int
+    L.crnn_last_kernel_times.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.crnn_last_error.restype = C.c_char_p
     L.crnn_last_error.argtypes = [vp]
     L.crnn_destroy.restype = None

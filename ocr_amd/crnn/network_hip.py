@@ -220,6 +220,52 @@ class CRNN(object):
         _capi.check(self._h, rc)
         return out
 
+    # --------------------------------------------------- device-resident batches
+    def stream_ptr(self):
+        """The handle's hipStream_t as an integer (for torch.cuda.ExternalStream / HIP events)."""
+        p = self._lib.crnn_stream(self._h)
+        if not p:
+            _capi.check(self._h, _capi.CRNN_ERR_HIP)
+        return p
+
+    def forward_device(self, d_gray_ptr, n, w, d_lab_ptr, d_len_ptr, d_raw_ptr=None, widths=None, sync=False):
+        """Lines already in HBM: uint8 [n,32,w] at d_gray_ptr -> collapsed labels [n,T] and lengths [n]
+        (device pointers).  Asynchronous on the handle's stream unless sync."""
+        wv = None
+        if widths is not None:
+            wv = np.ascontiguousarray(widths, dtype=np.int32)
+        rc = self._lib.crnn_forward_device(self._h, d_gray_ptr, n, w, wv.ctypes.data if wv is not None else None,
+                                           d_raw_ptr, d_lab_ptr, d_len_ptr, int(sync))
+        _capi.check(self._h, rc)
+
+    def synchronize(self):
+        _capi.check(self._h, self._lib.crnn_synchronize(self._h))
+
+    def texts_from_labels(self, lab, ln):
+        """Host arrays lab [n,T] / ln [n] (as copied back from forward_device) -> list of str."""
+        lab = np.asarray(lab)
+        ln = np.asarray(ln)
+        if self._alpha_cp is None:
+            return self._texts(lab, ln)
+        T = lab.shape[1]
+        mask = np.arange(T)[None, :] < ln[:, None]
+        s = self._alpha_cp[lab[mask]].astype("<u4").tobytes().decode("utf-32-le")
+        offs = np.concatenate(([0], np.cumsum(ln)))
+        return [s[offs[i]:offs[i + 1]] for i in range(len(ln))]
+
+    def set_profiling(self, on):
+        _capi.check(self._h, self._lib.crnn_set_profiling(self._h, int(on)))
+
+    def kernel_times(self):
+        """[(name, ms, flops, bytes)] per launch of the most recent forward_device (profiling on)."""
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        fl = (C.c_double * cap)()
+        by = (C.c_double * cap)()
+        n = _capi.check(self._h, self._lib.crnn_last_kernel_times(self._h, cap, names, ms, fl, by))
+        return [(names[i].decode(), ms[i], fl[i], by[i]) for i in range(n)]
+
     def timing(self):
         ms = (C.c_float * 5)()
         _capi.check(self._h, self._lib.crnn_last_timing(self._h, ms))

@@ -55,6 +55,13 @@ struct crnn_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
+  static constexpr int MAXK = 32;
+  hipEvent_t kev[MAXK + 1] = {};
+  const char* kname[MAXK] = {};
+  double kflop[MAXK] = {};
+  double kbytes[MAXK] = {};
+  int nk = 0;       // launches recorded by the last run
+  bool kprof = false;
   float* d_conv_w[7] = {};
   float* d_conv_b[7] = {};
   float* d_wih[2] = {};
@@ -130,6 +137,7 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < 5; i++) HIPCHK(h, hipEventCreate(&h->ev[i]));
+    for (int i = 0; i <= crnn_handle::MAXK; i++) HIPCHK(h, hipEventCreate(&h->kev[i]));
     upload_norm_lut(h->lut, h->stream);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->dev_pid = getpid();
@@ -256,16 +264,28 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
   return p;
 }
 
-void gemm(crnn_handle* h, const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K) {
+// Per-launch profiling (crnn_set_profiling): an event after every launch; name, algorithmic
+// FLOPs (2*MACs) and algorithmic bytes (compulsory reads + writes) of the launch it closes.
+void kmark(crnn_handle* h, const char* name, double flop, double bytes) {
+  if (!h->kprof || h->nk >= crnn_handle::MAXK) return;
+  h->kname[h->nk] = name; h->kflop[h->nk] = flop; h->kbytes[h->nk] = bytes;
+  h->nk++;
+  (void)hipEventRecord(h->kev[h->nk], h->stream);
+}
+
+void gemm(crnn_handle* h, const char* name, const float* A, const float* Wt, const float* bias, float* C, int M,
+          int N, int K) {
   ConvGemm p{};
   p.A = A; p.Wt = Wt; p.bias = bias; p.C = C; p.wvalid = nullptr;
   p.M = M; p.N = N; p.K = K; p.ldc = N;
   p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
   launch_conv_gemm(p, h->stream);
+  kmark(h, name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 }
 
 void conv(crnn_handle* h, int layer, const float* A, float* C, const int32_t* wvalid, int n, int Hin, int Win,
           int Cin, int Hout, int Wout) {
+  static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   ConvGemm p{};
   p.A = A; p.Wt = h->d_conv_w[layer]; p.bias = h->d_conv_b[layer]; p.C = C; p.wvalid = wvalid;
   p.M = n * Hout * Wout; p.N = NM[layer]; p.K = KS[layer] * KS[layer] * Cin; p.ldc = NM[layer];
@@ -273,6 +293,8 @@ void conv(crnn_handle* h, int layer, const float* A, float* C, const int32_t* wv
   p.ks = KS[layer]; p.pad = KS[layer] == 3 ? 1 : 0;
   p.act = h->cfg.leaky_relu ? 2 : 1;
   launch_conv_gemm(p, h->stream);
+  kmark(h, names[layer], 2.0 * p.M * p.N * p.K,
+        4.0 * ((double)n * Hin * Win * Cin + (double)p.N * p.K + (double)p.M * p.N));
 }
 
 // Runs the network on the normalised input already in plan.x.  widths: host
@@ -297,31 +319,41 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   }
   hipStream_t s = h->stream;
   HIPCHK(h, hipEventRecord(h->ev[1], s));
+  const double dn = n;
   launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
+  kmark(h, "conv0_pool0", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * (dn * 32 * g.W + dn * 16 * g.W1 * 64));
   conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1);
   launch_pool_2x2s2(p.c1, p.p1, n, 16, g.W1, 128, s);
+  kmark(h, "pool1", 0, 4.0 * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
   conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2);
   conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2);
   launch_pool_2x2s21p01(p.c3, p.p2, n, 8, g.W2, 256, s);
+  kmark(h, "pool2", 0, 4.0 * (dn * 8 * g.W2 * 256 + dn * 4 * g.W3 * 256));
   conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3);
   conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3);
   launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
+  kmark(h, "pool3", 0, 4.0 * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
   conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T);
   HIPCHK(h, hipEventRecord(h->ev[2], s));
   const int M = n * g.T;
+  const double recflop = 2.0 * M * 2 * 1024 * 256, recbytes = 4.0 * ((double)M * 2048 + (double)M * 512 + 2 * 1024 * 256);
   if (h->cfg.lstm) {
-    gemm(h, p.seq, h->d_wih[0], h->d_bih[0], p.xp, M, 2048, 512);
+    gemm(h, "lstm0_ih", p.seq, h->d_wih[0], h->d_bih[0], p.xp, M, 2048, 512);
     launch_lstm_rec(p.xp, h->d_whhp[0], p.rec0, tlen, n, g.T, s);
-    gemm(h, p.rec0, h->d_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512);
-    gemm(h, p.mid, h->d_wih[1], h->d_bih[1], p.xp, M, 2048, 256);
+    kmark(h, "lstm0_rec", recflop, recbytes);
+    gemm(h, "emb0", p.rec0, h->d_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512);
+    gemm(h, "lstm1_ih", p.mid, h->d_wih[1], h->d_bih[1], p.xp, M, 2048, 256);
     launch_lstm_rec(p.xp, h->d_whhp[1], p.rec1, tlen, n, g.T, s);
-    gemm(h, p.rec1, h->d_emb_w[1], h->d_emb_b[1], p.logits, M, h->cfg.nclass, 512);
+    kmark(h, "lstm1_rec", recflop, recbytes);
+    gemm(h, "classifier", p.rec1, h->d_emb_w[1], h->d_emb_b[1], p.logits, M, h->cfg.nclass, 512);
   } else {
-    gemm(h, p.seq, h->d_lin_w, h->d_lin_b, p.logits, M, h->cfg.nclass, 512);
+    gemm(h, "classifier", p.seq, h->d_lin_w, h->d_lin_b, p.logits, M, h->cfg.nclass, 512);
   }
   HIPCHK(h, hipEventRecord(h->ev[3], s));
   launch_argmax(p.logits, p.raw, M, h->cfg.nclass, h->cfg.nclass, s);
+  kmark(h, "argmax", 0, 4.0 * ((double)M * h->cfg.nclass + M));
   launch_ctc(p.raw, tlen, d_lab, d_len, n, g.T, s);
+  kmark(h, "ctc", 0, 4.0 * (2.0 * M + n));
   HIPCHK(h, hipEventRecord(h->ev[4], s));
   h->ev_valid = true;
   HIPCHK(h, hipGetLastError());
@@ -638,7 +670,10 @@ int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_
     HIPCHK(h, hipMemcpyAsync(d_w, widths, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
   }
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  h->nk = 0;
+  if (h->kprof) HIPCHK(h, hipEventRecord(h->kev[0], h->stream));
   launch_normalize(d_gray, p.x, d_w, n, w, w, h->stream);
+  kmark(h, "normalize", 0, (double)n * 32 * w * 5.0);
   if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
   if (d_raw)
     HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, h->stream));
@@ -695,6 +730,30 @@ int crnn_last_timing(crnn_handle* h, float ms[5]) {
   return 0;
 }
 
+int crnn_set_profiling(crnn_handle* h, int32_t on) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->kprof = on != 0;
+  h->nk = 0;
+  return 0;
+}
+
+int crnn_last_kernel_times(crnn_handle* h, int32_t cap, const char** names, float* ms, double* flops,
+                           double* bytes) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!h->kprof || h->nk == 0) return 0;
+  HIPCHK(h, hipEventSynchronize(h->kev[h->nk]));
+  int n = h->nk < cap ? h->nk : cap;
+  for (int i = 0; i < n; i++) {
+    if (names) names[i] = h->kname[i];
+    if (ms) HIPCHK(h, hipEventElapsedTime(&ms[i], h->kev[i], h->kev[i + 1]));
+    if (flops) flops[i] = h->kflop[i];
+    if (bytes) bytes[i] = h->kbytes[i];
+  }
+  return n;
+}
+
 const char* crnn_last_error(const crnn_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
 void crnn_destroy(crnn_handle* h) {
@@ -710,6 +769,7 @@ void crnn_destroy(crnn_handle* h) {
     (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b);
     (void)hipFree(h->arena.p); (void)hipFree(h->pre.p); (void)hipFree(h->io.p);
     for (int i = 0; i < 5; i++) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i <= crnn_handle::MAXK; i++) (void)hipEventDestroy(h->kev[i]);
     (void)hipStreamDestroy(h->stream);
   }
   delete h;
