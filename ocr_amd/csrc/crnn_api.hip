@@ -71,6 +71,7 @@ struct crnn_handle {
   float* d_emb_b[2] = {};
   float* d_lin_w = nullptr;
   float* d_lin_b = nullptr;
+  float* d_zero = nullptr;   // 256 bytes of zeros: source of conv padding taps
   DevBuf arena;      // activations
   DevBuf pre;        // preprocessing scratch (sources, temp, coefficients, jobs)
   DevBuf io;         // per-call small buffers (widths, outputs for the host path)
@@ -139,6 +140,8 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     for (int i = 0; i < 5; i++) HIPCHK(h, hipEventCreate(&h->ev[i]));
     for (int i = 0; i <= crnn_handle::MAXK; i++) HIPCHK(h, hipEventCreate(&h->kev[i]));
     upload_norm_lut(h->lut, h->stream);
+    HIPCHK(h, hipMalloc((void**)&h->d_zero, 256));
+    HIPCHK(h, hipMemset(h->d_zero, 0, 256));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->dev_pid = getpid();
     h->dev_ready = true;
@@ -276,7 +279,7 @@ void kmark(crnn_handle* h, const char* name, double flop, double bytes) {
 void gemm(crnn_handle* h, const char* name, const float* A, const float* Wt, const float* bias, float* C, int M,
           int N, int K) {
   ConvGemm p{};
-  p.A = A; p.Wt = Wt; p.bias = bias; p.C = C; p.wvalid = nullptr;
+  p.A = A; p.Wt = Wt; p.bias = bias; p.C = C; p.wvalid = nullptr; p.zero = h->d_zero;
   p.M = M; p.N = N; p.K = K; p.ldc = N;
   p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
   launch_conv_gemm(p, h->stream);
@@ -287,7 +290,7 @@ void conv(crnn_handle* h, int layer, const float* A, float* C, const int32_t* wv
           int Cin, int Hout, int Wout) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   ConvGemm p{};
-  p.A = A; p.Wt = h->d_conv_w[layer]; p.bias = h->d_conv_b[layer]; p.C = C; p.wvalid = wvalid;
+  p.A = A; p.Wt = h->d_conv_w[layer]; p.bias = h->d_conv_b[layer]; p.C = C; p.wvalid = wvalid; p.zero = h->d_zero;
   p.M = n * Hout * Wout; p.N = NM[layer]; p.K = KS[layer] * KS[layer] * Cin; p.ldc = NM[layer];
   p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
   p.ks = KS[layer]; p.pad = KS[layer] == 3 ? 1 : 0;
@@ -766,7 +769,7 @@ void crnn_destroy(crnn_handle* h) {
       (void)hipFree(h->d_wih[l]); (void)hipFree(h->d_bih[l]); (void)hipFree(h->d_whhp[l]);
       (void)hipFree(h->d_emb_w[l]); (void)hipFree(h->d_emb_b[l]);
     }
-    (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b);
+    (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->d_zero);
     (void)hipFree(h->arena.p); (void)hipFree(h->pre.p); (void)hipFree(h->io.p);
     for (int i = 0; i < 5; i++) (void)hipEventDestroy(h->ev[i]);
     for (int i = 0; i <= crnn_handle::MAXK; i++) (void)hipEventDestroy(h->kev[i]);

@@ -37,40 +37,52 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemm p) {
   const int lk = (tid & 7) * 4;
   const int hw = p.Hout * p.Wout;
 
-  int ay[4], ax[4];
-  long abase[4];
-  bool aval[4], bval[4];
-  const float* bptr[4];
+  // Loader state.  Rows beyond M / N are clamped to the last valid row (their results are never
+  // stored); taps that fall into the zero padding read 16 bytes of zeros from p.zero instead, so
+  // every load is unconditional and the loop body is one basic block.
+  const float* arow[4];   // &A[b][y-pad][x-pad][lk]  (may point outside the image; used only when the tap is valid)
+  unsigned amask[4];      // bit (ky*ks+kx): tap inside the image
+  const float* brow[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     int m = m0 + lrow + 32 * i;
-    aval[i] = m < p.M;
-    int mm = aval[i] ? m : 0;
-    int b = mm / hw, r = mm - b * hw;
-    int y = r / p.Wout, x = r - y * p.Wout;
-    abase[i] = (long)b * p.Hin * p.Win;
-    ay[i] = y - p.pad;
-    ax[i] = x - p.pad;
+    m = m < p.M ? m : p.M - 1;
+    const int b = m / hw, r = m - b * hw;
+    const int y = r / p.Wout, x = r - y * p.Wout;
+    arow[i] = p.A + (((long)b * p.Hin + (y - p.pad)) * p.Win + (x - p.pad)) * p.Cin + lk;
+    unsigned mk = 0;
+    for (int ky = 0; ky < p.ks; ky++)
+      for (int kx = 0; kx < p.ks; kx++) {
+        const int yy = y - p.pad + ky, xx = x - p.pad + kx;
+        if ((unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win) mk |= 1u << (ky * p.ks + kx);
+      }
+    amask[i] = mk;
     int n = n0 + lrow + 32 * i;
-    bval[i] = n < p.N;
-    bptr[i] = p.Wt + (long)(bval[i] ? n : 0) * p.K + lk;
+    n = n < p.N ? n : p.N - 1;
+    brow[i] = p.Wt + (long)n * p.K + lk;
   }
   const int nk = p.K / BK;
   f32x4 ra[4], rb[4];
+  // wave-uniform position of the NEXT tile to load: tap (ky,kx) and channel offset ci
+  int l_tap = 0, l_ky = 0, l_kx = 0, l_ci = 0, l_k0 = 0;
 
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-    const int tap = k0 / p.Cin;
-    const int ci = k0 - tap * p.Cin + lk;
-    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+  auto gload = [&]() {
+    const long toff = ((long)l_ky * p.Win + l_kx) * p.Cin + l_ci;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      int yy = ay[i] + ky, xx = ax[i] + kx;
-      bool ok = aval[i] && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      ra[i] = ok ? *(const f32x4*)(p.A + ((abase[i] + (long)yy * p.Win + xx) * p.Cin + ci)) : z;
-      rb[i] = bval[i] ? *(const f32x4*)(bptr[i] + k0) : z;
+      const float* src = ((amask[i] >> l_tap) & 1u) ? arow[i] + toff : p.zero;
+      ra[i] = *(const f32x4*)src;
+      rb[i] = *(const f32x4*)(brow[i] + l_k0);
     }
+    l_k0 += BK;
+    l_ci += BK;
+    const bool wrap_c = l_ci == p.Cin;
+    l_ci = wrap_c ? 0 : l_ci;
+    l_tap += wrap_c ? 1 : 0;
+    l_kx += wrap_c ? 1 : 0;
+    const bool wrap_x = l_kx == p.ks;
+    l_kx = wrap_x ? 0 : l_kx;
+    l_ky += wrap_x ? 1 : 0;
   };
   auto sstore = [&](int buf) {
     float* sa = smem + buf * (BM + BN) * LDT;
@@ -90,12 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemm p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+  auto compute = [&](int cur) {
     const float* a = smem + cur * (BM + BN) * LDT + (wm * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
     const float* b = smem + cur * (BM + BN) * LDT + BM * LDT + (wn * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
 #pragma unroll
@@ -112,9 +119,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemm p) {
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) sstore(cur ^ 1);
+  };
+
+  gload();
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk - 1; kt++) {
+    const int cur = kt & 1;
+    gload();            // tile kt+1 -> registers, in flight under the MFMAs of tile kt
+    compute(cur);
+    sstore(cur ^ 1);
     __syncthreads();
   }
+  compute((nk - 1) & 1);
 
   // epilogue: bias + activation + per-sample width mask.  C/D map of the 32x32
   // MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
