@@ -58,8 +58,9 @@ def cpu_baseline(lines_u8, sd, alphabet, want_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--lanes", type=int, default=3, help="independent stream/workspace lanes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -86,8 +87,9 @@ def main():
 
     sd = synth_state_dict(NCLASS, seed=0)
     model = CRNN(32, 1, NCLASS, 256, leakyRelu=False, lstmFlag=True, GPU=True, alphabet=keys.alphabetChinese,
-                 device=local_rank)
+                 device=local_rank, lanes=args.lanes)
     model.load_state_dict(sd)
+    NL = model.lanes
 
     # synthetic lines, resident in HBM before the timed region; a different batch per step slot
     nslots = 4
@@ -95,34 +97,37 @@ def main():
     host_lines = rs.randint(0, 256, size=(nslots, BATCH, 32, WIDTH)).astype(np.uint8)
     d_lines = torch.from_numpy(host_lines).to(dev)
     T = WIDTH // 4 + 1
-    d_lab = [torch.zeros((BATCH, T), dtype=torch.int32, device=dev) for _ in range(2)]
-    d_len = [torch.zeros((BATCH,), dtype=torch.int32, device=dev) for _ in range(2)]
-    h_lab = [torch.zeros((BATCH, T), dtype=torch.int32).pin_memory() for _ in range(2)]
-    h_len = [torch.zeros((BATCH,), dtype=torch.int32).pin_memory() for _ in range(2)]
-    ext = torch.cuda.ExternalStream(model.stream_ptr(), device=dev)
-    evs = [torch.cuda.Event() for _ in range(2)]
+    NS = NL + 1    # result slots: NL batches in flight + the one being read on the host
+    d_lab = [torch.zeros((BATCH, T), dtype=torch.int32, device=dev) for _ in range(NS)]
+    d_len = [torch.zeros((BATCH,), dtype=torch.int32, device=dev) for _ in range(NS)]
+    h_lab = [torch.zeros((BATCH, T), dtype=torch.int32).pin_memory() for _ in range(NS)]
+    h_len = [torch.zeros((BATCH,), dtype=torch.int32).pin_memory() for _ in range(NS)]
+    ext = [torch.cuda.ExternalStream(model.stream_ptr(l), device=dev) for l in range(NL)]
+    evs = [torch.cuda.Event() for _ in range(NS)]
 
     def launch(k):
-        s = k % 2
-        model.forward_device(d_lines[k % nslots].data_ptr(), BATCH, WIDTH, d_lab[s].data_ptr(), d_len[s].data_ptr())
-        with torch.cuda.stream(ext):
+        s = k % NS
+        lane = model.forward_device(d_lines[k % nslots].data_ptr(), BATCH, WIDTH, d_lab[s].data_ptr(),
+                                    d_len[s].data_ptr())
+        with torch.cuda.stream(ext[lane]):      # copy-back queued behind the batch on ITS lane
             h_lab[s].copy_(d_lab[s], non_blocking=True)
             h_len[s].copy_(d_len[s], non_blocking=True)
-            evs[s].record(ext)
+            evs[s].record(ext[lane])
 
     def collect(k):
-        s = k % 2
+        s = k % NS
         evs[s].synchronize()
         return model.texts_from_labels(h_lab[s].numpy(), h_len[s].numpy())
 
     def run(nsteps):
+        """nsteps batches; up to NL in flight on the device while the host decodes finished ones."""
         texts = None
         for k in range(nsteps):
             launch(k)
-            if k > 0:
-                texts = collect(k - 1)
-        if nsteps > 0:
-            texts = collect(nsteps - 1)
+            if k >= NL:
+                texts = collect(k - NL)
+        for k in range(max(0, nsteps - NL), nsteps):
+            texts = collect(k)
         return texts
 
     def barrier():
@@ -184,6 +189,7 @@ def main():
         "config": {"workload": "configs[1]: CRNN fp32, batch 256 synthetic 32x280 grayscale lines per step per GPU, "
                                "uint8 lines resident in HBM -> decoded strings on the host",
                    "batch": BATCH, "width": WIDTH, "nclass": NCLASS, "lines_per_step": BATCH * world,
+                   "lanes_per_gpu": NL,
                    "sharding": "independent lines, one replica per GPU, no collective"},
         "roofline": {
             "bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv1-6 + LSTM input projections + "

@@ -49,7 +49,7 @@ typedef struct {
   int32_t leaky_relu; /* leakyRelu */
   int32_t lstm;       /* lstmFlag */
   int32_t device;     /* HIP device ordinal (config.GPUID) */
-  int32_t reserved;
+  int32_t lanes;      /* independent (stream, workspace) lanes crnn_forward_device rotates over; 0 -> 1, max 4 */
 } crnn_config;
 
 /* One entry of the flat state dict CRNN.load_weights reads (network_torch.py:110-117):
@@ -106,7 +106,9 @@ CRNN_API int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, cons
  * width-bucketing scheduler and bench.py use): d_gray uint8 [n,32,w] device pointer; widths
  * host int32[n] (valid width of each line, <= w) or NULL when every line is w wide.
  * Outputs are DEVICE pointers: d_lab [n,T] int32, d_len [n] int32, d_raw [n,T] int32 or NULL,
- * with T = crnn_out_len(w).  Runs asynchronously on the handle's stream unless sync != 0.
+ * with T = crnn_out_len(w).  Runs asynchronously unless sync != 0.  Successive calls rotate over
+ * the handle's lanes (crnn_config.lanes): the call returns the lane index (>= 0) it was queued
+ * on, whose stream is crnn_stream(h, lane); work on different lanes overlaps on the device.
  * No reference counterpart (the reference never keeps data on a device). */
 CRNN_API int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_t w,
                         const int32_t* widths, int32_t* d_raw, int32_t* d_lab, int32_t* d_len,
@@ -119,12 +121,13 @@ CRNN_API int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t 
 CRNN_API int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const int32_t* widths,
                      int32_t stage, float* out_host, int64_t out_floats);
 
-/* Blocks until everything queued on the handle's stream has finished. */
+/* Blocks until everything queued on every lane of the handle has finished. */
 CRNN_API int crnn_synchronize(crnn_handle* h);
 
-/* The HIP stream (hipStream_t as void*) the handle launches on, for callers that time with
- * HIP events or order their own work against it. */
-CRNN_API void* crnn_stream(crnn_handle* h);
+/* The HIP stream (hipStream_t as void*) of one lane, for callers that time with HIP events or
+ * order their own work (e.g. the copy-back of results) against it.  crnn_lanes: lane count. */
+CRNN_API void* crnn_stream(crnn_handle* h, int32_t lane);
+CRNN_API int crnn_lanes(const crnn_handle* h);
 
 /* Device time of the most recent crnn_forward_device / crnn_predict_batch in ms (HIP events
  * on the handle's stream), split by stage: [0] preprocess, [1] conv stack, [2] lstm+linear,

@@ -16,13 +16,13 @@ CRNN_ERR_ARG, CRNN_ERR_HIP, CRNN_ERR_STATE, CRNN_ERR_ZERO_H, CRNN_ERR_ZERO_W, CR
 PAD_PER_LINE, PAD_REFERENCE = 0, 1
 
 SYMBOLS = ["crnn_create", "crnn_load_weights", "crnn_resized_width", "crnn_out_len", "crnn_preprocess",
-           "crnn_predict_batch", "crnn_forward_device", "crnn_debug_stage", "crnn_synchronize", "crnn_stream",
+           "crnn_predict_batch", "crnn_forward_device", "crnn_debug_stage", "crnn_synchronize", "crnn_stream", "crnn_lanes",
            "crnn_last_timing", "crnn_set_profiling", "crnn_last_kernel_times", "crnn_last_error", "crnn_destroy"]
 
 
 class Config(C.Structure):
     _fields_ = [("img_h", C.c_int32), ("nc", C.c_int32), ("nclass", C.c_int32), ("nh", C.c_int32),
-                ("leaky_relu", C.c_int32), ("lstm", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("leaky_relu", C.c_int32), ("lstm", C.c_int32), ("device", C.c_int32), ("lanes", C.c_int32)]
 
 
 class Tensor(C.Structure):
@@ -61,7 +61,9 @@ def lib():
     L.crnn_synchronize.restype = C.c_int
     L.crnn_synchronize.argtypes = [vp]
     L.crnn_stream.restype = vp
-    L.crnn_stream.argtypes = [vp]
+    L.crnn_stream.argtypes = [vp, i32]
+    L.crnn_lanes.restype = C.c_int
+    L.crnn_lanes.argtypes = [vp]
     L.crnn_last_timing.restype = C.c_int
     L.crnn_last_timing.argtypes = [vp, C.POINTER(C.c_float)]
     L.crnn_set_profiling.restype = C.c_int

@@ -37,7 +37,8 @@ def _as_gray_array(image):
 class CRNN(object):
     """Same surface as ``crnn.network_torch.CRNN``; inference only."""
 
-    def __init__(self, imgH, nc, nclass, nh, leakyRelu=False, lstmFlag=True, GPU=False, alphabet=None, device=None):
+    def __init__(self, imgH, nc, nclass, nh, leakyRelu=False, lstmFlag=True, GPU=False, alphabet=None, device=None,
+                 lanes=1):
         assert imgH % 16 == 0, 'imgH has to be a multiple of 16'
         if imgH != 32 or nc != 1 or nh != 256:
             raise ValueError("the HIP path implements the shipped configuration: imgH=32, nc=1, nh=256")
@@ -49,7 +50,7 @@ class CRNN(object):
             device = int(os.environ.get("CRNN_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         self.device = device
         self._lib = _capi.lib()
-        cfg = _capi.Config(imgH, nc, nclass, nh, int(bool(leakyRelu)), int(bool(lstmFlag)), device, 0)
+        cfg = _capi.Config(imgH, nc, nclass, nh, int(bool(leakyRelu)), int(bool(lstmFlag)), device, lanes)
         h = C.c_void_p()
         rc = self._lib.crnn_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -221,22 +222,26 @@ class CRNN(object):
         return out
 
     # --------------------------------------------------- device-resident batches
-    def stream_ptr(self):
-        """The handle's hipStream_t as an integer (for torch.cuda.ExternalStream / HIP events)."""
-        p = self._lib.crnn_stream(self._h)
+    @property
+    def lanes(self):
+        return self._lib.crnn_lanes(self._h)
+
+    def stream_ptr(self, lane=0):
+        """hipStream_t of one lane as an integer (for torch.cuda.ExternalStream / HIP events)."""
+        p = self._lib.crnn_stream(self._h, lane)
         if not p:
             _capi.check(self._h, _capi.CRNN_ERR_HIP)
         return p
 
     def forward_device(self, d_gray_ptr, n, w, d_lab_ptr, d_len_ptr, d_raw_ptr=None, widths=None, sync=False):
         """Lines already in HBM: uint8 [n,32,w] at d_gray_ptr -> collapsed labels [n,T] and lengths [n]
-        (device pointers).  Asynchronous on the handle's stream unless sync."""
+        (device pointers).  Asynchronous unless sync; returns the lane the batch was queued on."""
         wv = None
         if widths is not None:
             wv = np.ascontiguousarray(widths, dtype=np.int32)
         rc = self._lib.crnn_forward_device(self._h, d_gray_ptr, n, w, wv.ctypes.data if wv is not None else None,
                                            d_raw_ptr, d_lab_ptr, d_len_ptr, int(sync))
-        _capi.check(self._h, rc)
+        return _capi.check(self._h, rc)
 
     def synchronize(self):
         _capi.check(self._h, self._lib.crnn_synchronize(self._h))

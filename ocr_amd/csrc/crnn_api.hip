@@ -35,6 +35,25 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+constexpr int MAX_LANES = 4;
+constexpr int MAXK = 32;
+
+struct Lane {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+  hipEvent_t kev[MAXK + 1] = {};
+  const char* kname[MAXK] = {};
+  double kflop[MAXK] = {};
+  double kbytes[MAXK] = {};
+  int nk = 0;        // launches recorded by the last run
+  DevBuf arena;      // activations
+  DevBuf pre;        // preprocessing scratch (sources, temp, coefficients, jobs)
+  DevBuf io;         // per-call small buffers (outputs of the host path)
+  float* st[11] = {};          // where the stages of the last run live (crnn_debug_stage)
+  size_t st_floats[11] = {};
+};
+
 }  // namespace
 
 struct crnn_handle {
@@ -52,16 +71,6 @@ struct crnn_handle {
   pid_t dev_pid = 0;
   bool dev_ready = false;
   bool weights_on_dev = false;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool ev_valid = false;
-  static constexpr int MAXK = 32;
-  hipEvent_t kev[MAXK + 1] = {};
-  const char* kname[MAXK] = {};
-  double kflop[MAXK] = {};
-  double kbytes[MAXK] = {};
-  int nk = 0;       // launches recorded by the last run
-  bool kprof = false;
   float* d_conv_w[7] = {};
   float* d_conv_b[7] = {};
   float* d_wih[2] = {};
@@ -72,13 +81,16 @@ struct crnn_handle {
   float* d_lin_w = nullptr;
   float* d_lin_b = nullptr;
   float* d_zero = nullptr;   // 256 bytes of zeros: source of conv padding taps
-  DevBuf arena;      // activations
-  DevBuf pre;        // preprocessing scratch (sources, temp, coefficients, jobs)
-  DevBuf io;         // per-call small buffers (widths, outputs for the host path)
+  bool kprof = false;
 
-  // layout of the last run inside the arena (for crnn_debug_stage)
-  float* st[11] = {};
-  size_t st_floats[11] = {};
+  // Lanes: independent (stream, workspace) pairs.  Successive crnn_forward_device calls go to
+  // successive lanes, so the latency-bound LSTM recurrence of one batch (32 workgroups) runs
+  // beside the conv stack of the next batch and kernel tails of one lane are filled by another.
+  Lane lanes[MAX_LANES];
+  int nlanes = 1;
+  int next_lane = 0;
+  Lane* cur = &lanes[0];     // lane of the call in progress (set under mu)
+  Lane* last = &lanes[0];    // lane of the most recent network run (timing / debug queries)
 };
 
 namespace {
@@ -98,7 +110,7 @@ int fail(const crnn_handle* h, int code, const std::string& msg) {
 int ensure_buf(crnn_handle* h, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return 0;
   if (b.p) {
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur->stream));
     HIPCHK(h, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -126,8 +138,11 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     // belong to its context -- drop them, do not free)
     h->dev_ready = false;
     h->weights_on_dev = false;
-    h->ev_valid = false;
-    h->arena = DevBuf(); h->pre = DevBuf(); h->io = DevBuf();
+    for (Lane& L : h->lanes) {
+      L.ev_valid = false;
+      L.nk = 0;
+      L.arena = DevBuf(); L.pre = DevBuf(); L.io = DevBuf();
+    }
   }
   if (!h->dev_ready) {
     int ndev = 0;
@@ -136,13 +151,16 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       return fail(h, CRNN_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
     if (h->cfg.device < 0 || h->cfg.device >= ndev) return fail(h, CRNN_ERR_ARG, "device ordinal out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 5; i++) HIPCHK(h, hipEventCreate(&h->ev[i]));
-    for (int i = 0; i <= crnn_handle::MAXK; i++) HIPCHK(h, hipEventCreate(&h->kev[i]));
-    upload_norm_lut(h->lut, h->stream);
+    for (int l = 0; l < h->nlanes; l++) {
+      Lane& L = h->lanes[l];
+      HIPCHK(h, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+      for (int i = 0; i < 5; i++) HIPCHK(h, hipEventCreate(&L.ev[i]));
+      for (int i = 0; i <= MAXK; i++) HIPCHK(h, hipEventCreate(&L.kev[i]));
+    }
+    upload_norm_lut(h->lut, h->cur->stream);
     HIPCHK(h, hipMalloc((void**)&h->d_zero, 256));
     HIPCHK(h, hipMemset(h->d_zero, 0, 256));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur->stream));
     h->dev_pid = getpid();
     h->dev_ready = true;
   } else {
@@ -270,10 +288,10 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
 // Per-launch profiling (crnn_set_profiling): an event after every launch; name, algorithmic
 // FLOPs (2*MACs) and algorithmic bytes (compulsory reads + writes) of the launch it closes.
 void kmark(crnn_handle* h, const char* name, double flop, double bytes) {
-  if (!h->kprof || h->nk >= crnn_handle::MAXK) return;
-  h->kname[h->nk] = name; h->kflop[h->nk] = flop; h->kbytes[h->nk] = bytes;
-  h->nk++;
-  (void)hipEventRecord(h->kev[h->nk], h->stream);
+  if (!h->kprof || h->cur->nk >= MAXK) return;
+  h->cur->kname[h->cur->nk] = name; h->cur->kflop[h->cur->nk] = flop; h->cur->kbytes[h->cur->nk] = bytes;
+  h->cur->nk++;
+  (void)hipEventRecord(h->cur->kev[h->cur->nk], h->cur->stream);
 }
 
 void gemm(crnn_handle* h, const char* name, const float* A, const float* Wt, const float* bias, float* C, int M,
@@ -282,7 +300,7 @@ void gemm(crnn_handle* h, const char* name, const float* A, const float* Wt, con
   p.A = A; p.Wt = Wt; p.bias = bias; p.C = C; p.wvalid = nullptr; p.zero = h->d_zero;
   p.M = M; p.N = N; p.K = K; p.ldc = N;
   p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
-  launch_conv_gemm(p, h->stream);
+  launch_conv_gemm(p, h->cur->stream);
   kmark(h, name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 }
 
@@ -295,7 +313,7 @@ void conv(crnn_handle* h, int layer, const float* A, float* C, const int32_t* wv
   p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
   p.ks = KS[layer]; p.pad = KS[layer] == 3 ? 1 : 0;
   p.act = h->cfg.leaky_relu ? 2 : 1;
-  launch_conv_gemm(p, h->stream);
+  launch_conv_gemm(p, h->cur->stream);
   kmark(h, names[layer], 2.0 * p.M * p.N * p.K,
         4.0 * ((double)n * Hin * Win * Cin + (double)p.N * p.K + (double)p.M * p.N));
 }
@@ -316,12 +334,12 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       wl[2 * n + i] = w2;            // conv2, conv3
       wl[3 * n + i] = w3;            // conv4, conv5 ; also T_i
     }
-    HIPCHK(h, hipMemcpyAsync(p.wl, wl.data(), sizeof(int32_t) * 4 * n, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // wl is a stack temporary
+    HIPCHK(h, hipMemcpyAsync(p.wl, wl.data(), sizeof(int32_t) * 4 * n, hipMemcpyHostToDevice, h->cur->stream));
+    HIPCHK(h, hipStreamSynchronize(h->cur->stream));  // wl is a stack temporary
     m_p0 = p.wl; m_c1 = p.wl + n; m_w2 = p.wl + 2 * n; m_w3 = p.wl + 3 * n; tlen = m_w3;
   }
-  hipStream_t s = h->stream;
-  HIPCHK(h, hipEventRecord(h->ev[1], s));
+  hipStream_t s = h->cur->stream;
+  HIPCHK(h, hipEventRecord(h->cur->ev[1], s));
   const double dn = n;
   launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
   kmark(h, "conv0_pool0", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * (dn * 32 * g.W + dn * 16 * g.W1 * 64));
@@ -337,7 +355,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
   kmark(h, "pool3", 0, 4.0 * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
   conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T);
-  HIPCHK(h, hipEventRecord(h->ev[2], s));
+  HIPCHK(h, hipEventRecord(h->cur->ev[2], s));
   const int M = n * g.T;
   const double recflop = 2.0 * M * 2 * 1024 * 256, recbytes = 4.0 * ((double)M * 2048 + (double)M * 512 + 2 * 1024 * 256);
   if (h->cfg.lstm) {
@@ -352,13 +370,14 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   } else {
     gemm(h, "classifier", p.seq, h->d_lin_w, h->d_lin_b, p.logits, M, h->cfg.nclass, 512);
   }
-  HIPCHK(h, hipEventRecord(h->ev[3], s));
+  HIPCHK(h, hipEventRecord(h->cur->ev[3], s));
   launch_argmax(p.logits, p.raw, M, h->cfg.nclass, h->cfg.nclass, s);
   kmark(h, "argmax", 0, 4.0 * ((double)M * h->cfg.nclass + M));
   launch_ctc(p.raw, tlen, d_lab, d_len, n, g.T, s);
   kmark(h, "ctc", 0, 4.0 * (2.0 * M + n));
-  HIPCHK(h, hipEventRecord(h->ev[4], s));
-  h->ev_valid = true;
+  HIPCHK(h, hipEventRecord(h->cur->ev[4], s));
+  h->cur->ev_valid = true;
+  h->last = h->cur;
   HIPCHK(h, hipGetLastError());
   // remember where the stages live
   float* st[11] = {p.p0, p.p1, p.c2, p.p2, p.c4, p.p3, p.seq, p.mid, p.rec0, p.rec1, p.logits};
@@ -366,15 +385,15 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
                    (size_t)n * 4 * g.W3 * 256, (size_t)n * 4 * g.W3 * 512, (size_t)n * 2 * g.W4 * 512,
                    (size_t)M * 512, (size_t)M * 256, (size_t)M * 512, (size_t)M * 512,
                    (size_t)M * h->cfg.nclass};
-  for (int i = 0; i < 11; i++) { h->st[i] = st[i]; h->st_floats[i] = sz[i]; }
+  for (int i = 0; i < 11; i++) { h->cur->st[i] = st[i]; h->cur->st_floats[i] = sz[i]; }
   return 0;
 }
 
 int prepare_plan(crnn_handle* h, const Geo& g, Plan& p) {
   Plan probe = make_plan(h, g, nullptr);
-  int rc = ensure_buf(h, h->arena, probe.bytes);
+  int rc = ensure_buf(h, h->cur->arena, probe.bytes);
   if (rc) return rc;
-  p = make_plan(h, g, (char*)h->arena.p);
+  p = make_plan(h, g, (char*)h->cur->arena.p);
   return 0;
 }
 
@@ -424,17 +443,17 @@ int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* he
   }
   const size_t a = (src_bytes + 255) / 256 * 256, b = (tmp_bytes + 255) / 256 * 256;
   const size_t c = (coef.size() * 4 + 255) / 256 * 256, d = (jobs.size() * sizeof(ResizeJob) + 255) / 256 * 256;
-  int rc = ensure_buf(h, h->pre, a + b + c + d);
+  int rc = ensure_buf(h, h->cur->pre, a + b + c + d);
   if (rc) return rc;
-  uint8_t* d_src = (uint8_t*)h->pre.p;
+  uint8_t* d_src = (uint8_t*)h->cur->pre.p;
   uint8_t* d_tmp = d_src + a;
   int32_t* d_coef = (int32_t*)(d_tmp + b);
   ResizeJob* d_jobs = (ResizeJob*)((char*)d_coef + c);
-  hipStream_t s = h->stream;
+  hipStream_t s = h->cur->stream;
   HIPCHK(h, hipMemcpyAsync(d_src, src.data(), src_bytes, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(d_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(ResizeJob), hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipEventRecord(h->ev[0], s));
+  HIPCHK(h, hipEventRecord(h->cur->ev[0], s));
   launch_resize_h(d_src, d_jobs, d_coef, d_tmp, nb, max_th, max_dw, s);
   launch_resize_v(d_src, d_jobs, d_coef, d_tmp, d_x, nb, Wp, s);
   HIPCHK(h, hipStreamSynchronize(s));  // host staging vectors go out of scope
@@ -467,6 +486,7 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   crnn_handle* h = new (std::nothrow) crnn_handle();
   if (!h) return CRNN_ERR_NOMEM;
   h->cfg = *cfg;
+  h->nlanes = cfg->lanes <= 0 ? 1 : (cfg->lanes > MAX_LANES ? MAX_LANES : cfg->lanes);
   for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);
   *out = h;
   return 0;
@@ -575,6 +595,7 @@ int crnn_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* h
                     int32_t* out_w) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
+  h->cur = &h->lanes[0];
   if (n <= 0 || !out_host || !out_w) return fail(h, CRNN_ERR_ARG, "bad arguments");
   int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
   if (rc) return rc;
@@ -587,10 +608,10 @@ int crnn_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* h
   }
   if ((rc = ensure_device(h, false))) return rc;
   const size_t bytes = (size_t)n * 32 * wp * sizeof(float);
-  if ((rc = ensure_buf(h, h->arena, bytes))) return rc;
-  if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, wp, (float*)h->arena.p)))
+  if ((rc = ensure_buf(h, h->cur->arena, bytes))) return rc;
+  if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, wp, (float*)h->cur->arena.p)))
     return rc;
-  HIPCHK(h, hipMemcpy(out_host, h->arena.p, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out_host, h->cur->arena.p, bytes, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -600,6 +621,7 @@ int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t
                        float* out_logits) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
+  h->cur = &h->lanes[0];
   if (n <= 0 || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
   if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
   int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
@@ -623,18 +645,18 @@ int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t
   Plan p;
   if ((rc = prepare_plan(h, g, p))) return rc;
   const size_t nT = (size_t)g.n * g.T;
-  if ((rc = ensure_buf(h, h->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
-  int32_t* d_lab = (int32_t*)h->io.p;
+  if ((rc = ensure_buf(h, h->cur->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
+  int32_t* d_lab = (int32_t*)h->cur->io.p;
   int32_t* d_len = d_lab + ((nT + 63) / 64) * 64;
   if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, Wp, p.x))) return rc;
   std::vector<int32_t> wv(dw.begin(), dw.end());
   const bool uniform = pad_mode == CRNN_PAD_REFERENCE;
   if ((rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len))) return rc;
   std::vector<int32_t> lab(nT), raw(nT), len(g.n);
-  HIPCHK(h, hipMemcpyAsync(lab.data(), d_lab, nT * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(raw.data(), p.raw, nT * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(len.data(), d_len, (size_t)g.n * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpyAsync(lab.data(), d_lab, nT * 4, hipMemcpyDeviceToHost, h->cur->stream));
+  HIPCHK(h, hipMemcpyAsync(raw.data(), p.raw, nT * 4, hipMemcpyDeviceToHost, h->cur->stream));
+  HIPCHK(h, hipMemcpyAsync(len.data(), d_len, (size_t)g.n * 4, hipMemcpyDeviceToHost, h->cur->stream));
+  HIPCHK(h, hipStreamSynchronize(h->cur->stream));
   std::vector<float> lg;
   if (out_logits) {
     lg.resize(nT * (size_t)h->cfg.nclass);
@@ -662,6 +684,9 @@ int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_
   if (widths)
     for (int i = 0; i < n; i++)
       if (widths[i] < 8 || widths[i] > w) return fail(h, CRNN_ERR_ARG, "line width outside [8, w]");
+  const int lane = h->next_lane;
+  h->next_lane = (h->next_lane + 1) % h->nlanes;
+  h->cur = &h->lanes[lane];
   int rc = ensure_device(h);
   if (rc) return rc;
   const Geo g(n, w);
@@ -670,24 +695,25 @@ int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_
   int32_t* d_w = nullptr;
   if (widths) {
     d_w = p.wl + 4 * (size_t)n;
-    HIPCHK(h, hipMemcpyAsync(d_w, widths, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_w, widths, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->cur->stream));
   }
-  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  h->nk = 0;
-  if (h->kprof) HIPCHK(h, hipEventRecord(h->kev[0], h->stream));
-  launch_normalize(d_gray, p.x, d_w, n, w, w, h->stream);
+  HIPCHK(h, hipEventRecord(h->cur->ev[0], h->cur->stream));
+  h->cur->nk = 0;
+  if (h->kprof) HIPCHK(h, hipEventRecord(h->cur->kev[0], h->cur->stream));
+  launch_normalize(d_gray, p.x, d_w, n, w, w, h->cur->stream);
   kmark(h, "normalize", 0, (double)n * 32 * w * 5.0);
   if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
   if (d_raw)
-    HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, h->stream));
-  if (sync) HIPCHK(h, hipStreamSynchronize(h->stream));
-  return 0;
+    HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, h->cur->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+  return lane;
 }
 
 int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const int32_t* widths, int32_t stage,
                      float* out_host, int64_t out_floats) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
+  h->cur = &h->lanes[0];
   if (!x || n <= 0 || w < 4 || stage < 0 || stage > 10 || !out_host) return fail(h, CRNN_ERR_ARG, "bad arguments");
   int rc = ensure_device(h);
   if (rc) return rc;
@@ -695,15 +721,15 @@ int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const
   Plan p;
   if ((rc = prepare_plan(h, g, p))) return rc;
   const size_t nT = (size_t)g.n * g.T;
-  if ((rc = ensure_buf(h, h->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
-  int32_t* d_lab = (int32_t*)h->io.p;
+  if ((rc = ensure_buf(h, h->cur->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
+  int32_t* d_lab = (int32_t*)h->cur->io.p;
   int32_t* d_len = d_lab + ((nT + 63) / 64) * 64;
-  HIPCHK(h, hipMemcpyAsync(p.x, x, sizeof(float) * (size_t)n * 32 * w, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  HIPCHK(h, hipMemcpyAsync(p.x, x, sizeof(float) * (size_t)n * 32 * w, hipMemcpyHostToDevice, h->cur->stream));
+  HIPCHK(h, hipEventRecord(h->cur->ev[0], h->cur->stream));
   if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  if ((size_t)out_floats < h->st_floats[stage]) return fail(h, CRNN_ERR_ARG, "out_host too small for this stage");
-  HIPCHK(h, hipMemcpy(out_host, h->st[stage], h->st_floats[stage] * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+  if ((size_t)out_floats < h->cur->st_floats[stage]) return fail(h, CRNN_ERR_ARG, "out_host too small for this stage");
+  HIPCHK(h, hipMemcpy(out_host, h->cur->st[stage], h->cur->st_floats[stage] * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -712,24 +738,28 @@ int crnn_synchronize(crnn_handle* h) {
   std::lock_guard<std::mutex> lk(h->mu);
   if (!h->dev_ready) return 0;
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int l = 0; l < h->nlanes; l++) HIPCHK(h, hipStreamSynchronize(h->lanes[l].stream));
   return 0;
 }
 
-void* crnn_stream(crnn_handle* h) {
-  if (!h) return nullptr;
+void* crnn_stream(crnn_handle* h, int32_t lane) {
+  if (!h || lane < 0) return nullptr;
   std::lock_guard<std::mutex> lk(h->mu);
+  if (lane >= h->nlanes) return nullptr;
   if (ensure_device(h, false)) return nullptr;
-  return (void*)h->stream;
+  return (void*)h->lanes[lane].stream;
 }
+
+int crnn_lanes(const crnn_handle* h) { return h ? h->nlanes : CRNN_ERR_ARG; }
 
 int crnn_last_timing(crnn_handle* h, float ms[5]) {
   if (!h || !ms) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  if (!h->ev_valid) return fail(h, CRNN_ERR_STATE, "nothing has run yet");
-  HIPCHK(h, hipEventSynchronize(h->ev[4]));
-  for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
-  HIPCHK(h, hipEventElapsedTime(&ms[4], h->ev[0], h->ev[4]));
+  Lane& L = *h->last;
+  if (!L.ev_valid) return fail(h, CRNN_ERR_STATE, "nothing has run yet");
+  HIPCHK(h, hipEventSynchronize(L.ev[4]));
+  for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], L.ev[i], L.ev[i + 1]));
+  HIPCHK(h, hipEventElapsedTime(&ms[4], L.ev[0], L.ev[4]));
   return 0;
 }
 
@@ -737,7 +767,7 @@ int crnn_set_profiling(crnn_handle* h, int32_t on) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
   h->kprof = on != 0;
-  h->nk = 0;
+  for (Lane& L : h->lanes) L.nk = 0;
   return 0;
 }
 
@@ -745,14 +775,15 @@ int crnn_last_kernel_times(crnn_handle* h, int32_t cap, const char** names, floa
                            double* bytes) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  if (!h->kprof || h->nk == 0) return 0;
-  HIPCHK(h, hipEventSynchronize(h->kev[h->nk]));
-  int n = h->nk < cap ? h->nk : cap;
+  Lane& L = *h->last;
+  if (!h->kprof || L.nk == 0) return 0;
+  HIPCHK(h, hipEventSynchronize(L.kev[L.nk]));
+  int n = L.nk < cap ? L.nk : cap;
   for (int i = 0; i < n; i++) {
-    if (names) names[i] = h->kname[i];
-    if (ms) HIPCHK(h, hipEventElapsedTime(&ms[i], h->kev[i], h->kev[i + 1]));
-    if (flops) flops[i] = h->kflop[i];
-    if (bytes) bytes[i] = h->kbytes[i];
+    if (names) names[i] = L.kname[i];
+    if (ms) HIPCHK(h, hipEventElapsedTime(&ms[i], L.kev[i], L.kev[i + 1]));
+    if (flops) flops[i] = L.kflop[i];
+    if (bytes) bytes[i] = L.kbytes[i];
   }
   return n;
 }
@@ -763,17 +794,20 @@ void crnn_destroy(crnn_handle* h) {
   if (!h) return;
   if (h->dev_ready && h->dev_pid == getpid()) {
     (void)hipSetDevice(h->cfg.device);
-    (void)hipStreamSynchronize(h->stream);
+    for (int l = 0; l < h->nlanes; l++) (void)hipStreamSynchronize(h->lanes[l].stream);
     for (int i = 0; i < 7; i++) { (void)hipFree(h->d_conv_w[i]); (void)hipFree(h->d_conv_b[i]); }
     for (int l = 0; l < 2; l++) {
       (void)hipFree(h->d_wih[l]); (void)hipFree(h->d_bih[l]); (void)hipFree(h->d_whhp[l]);
       (void)hipFree(h->d_emb_w[l]); (void)hipFree(h->d_emb_b[l]);
     }
     (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->d_zero);
-    (void)hipFree(h->arena.p); (void)hipFree(h->pre.p); (void)hipFree(h->io.p);
-    for (int i = 0; i < 5; i++) (void)hipEventDestroy(h->ev[i]);
-    for (int i = 0; i <= crnn_handle::MAXK; i++) (void)hipEventDestroy(h->kev[i]);
-    (void)hipStreamDestroy(h->stream);
+    for (int l = 0; l < h->nlanes; l++) {
+      Lane& L = h->lanes[l];
+      (void)hipFree(L.arena.p); (void)hipFree(L.pre.p); (void)hipFree(L.io.p);
+      for (int i = 0; i < 5; i++) (void)hipEventDestroy(L.ev[i]);
+      for (int i = 0; i <= MAXK; i++) (void)hipEventDestroy(L.kev[i]);
+      (void)hipStreamDestroy(L.stream);
+    }
   }
   delete h;
 }
