@@ -7,6 +7,7 @@
 
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -80,7 +81,6 @@ struct crnn_handle {
   float* d_emb_b[2] = {};
   float* d_lin_w = nullptr;
   float* d_lin_b = nullptr;
-  float* d_zero = nullptr;   // 256 bytes of zeros: source of conv padding taps
   bool kprof = false;
 
   // Lanes: independent (stream, workspace) pairs.  Successive crnn_forward_device calls go to
@@ -158,8 +158,6 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       for (int i = 0; i <= MAXK; i++) HIPCHK(h, hipEventCreate(&L.kev[i]));
     }
     upload_norm_lut(h->lut, h->cur->stream);
-    HIPCHK(h, hipMalloc((void**)&h->d_zero, 256));
-    HIPCHK(h, hipMemset(h->d_zero, 0, 256));
     HIPCHK(h, hipStreamSynchronize(h->cur->stream));
     h->dev_pid = getpid();
     h->dev_ready = true;
@@ -297,7 +295,7 @@ void kmark(crnn_handle* h, const char* name, double flop, double bytes) {
 void gemm(crnn_handle* h, const char* name, const float* A, const float* Wt, const float* bias, float* C, int M,
           int N, int K) {
   ConvGemm p{};
-  p.A = A; p.Wt = Wt; p.bias = bias; p.C = C; p.wvalid = nullptr; p.zero = h->d_zero;
+  p.A = A; p.Wt = Wt; p.bias = bias; p.C = C; p.wvalid = nullptr;
   p.M = M; p.N = N; p.K = K; p.ldc = N;
   p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
   launch_conv_gemm(p, h->cur->stream);
@@ -308,7 +306,7 @@ void conv(crnn_handle* h, int layer, const float* A, float* C, const int32_t* wv
           int Cin, int Hout, int Wout) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   ConvGemm p{};
-  p.A = A; p.Wt = h->d_conv_w[layer]; p.bias = h->d_conv_b[layer]; p.C = C; p.wvalid = wvalid; p.zero = h->d_zero;
+  p.A = A; p.Wt = h->d_conv_w[layer]; p.bias = h->d_conv_b[layer]; p.C = C; p.wvalid = wvalid;
   p.M = n * Hout * Wout; p.N = NM[layer]; p.K = KS[layer] * KS[layer] * Cin; p.ldc = NM[layer];
   p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
   p.ks = KS[layer]; p.pad = KS[layer] == 3 ? 1 : 0;
@@ -390,6 +388,10 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
 }
 
 int prepare_plan(crnn_handle* h, const Geo& g, Plan& p) {
+  // conv_gemm_kernel addresses its operands with 32-bit byte offsets (raw buffer loads)
+  const double big = 4.0 * g.n * std::max(std::max(16.0 * g.W1 * 64, 8.0 * g.W2 * 256), 4.0 * g.W3 * 512);
+  if (big >= 2147000000.0)
+    return fail(h, CRNN_ERR_ARG, "batch too large (an activation tensor exceeds 2 GiB): split the batch");
   Plan probe = make_plan(h, g, nullptr);
   int rc = ensure_buf(h, h->cur->arena, probe.bytes);
   if (rc) return rc;
@@ -800,7 +802,7 @@ void crnn_destroy(crnn_handle* h) {
       (void)hipFree(h->d_wih[l]); (void)hipFree(h->d_bih[l]); (void)hipFree(h->d_whhp[l]);
       (void)hipFree(h->d_emb_w[l]); (void)hipFree(h->d_emb_b[l]);
     }
-    (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->d_zero);
+    (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b);
     for (int l = 0; l < h->nlanes; l++) {
       Lane& L = h->lanes[l];
       (void)hipFree(L.arena.p); (void)hipFree(L.pre.p); (void)hipFree(L.io.p);

@@ -17,7 +17,6 @@ struct ConvGemm {
   const float* bias;  // [N]
   float* C;           // [M][ldc]
   const int32_t* wvalid;  // per-sample valid output width (x >= wvalid[b] -> 0) or nullptr
-  const float* zero;      // >= 16 bytes of zeros (source of padding taps)
   int M, N, K, ldc;
   int Hin, Win, Cin, Hout, Wout, ks, pad;
   int act;            // 0 none, 1 ReLU, 2 LeakyReLU(0.2)

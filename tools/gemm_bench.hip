@@ -1,0 +1,387 @@
+// Standalone micro-benchmark for variants of the implicit-GEMM conv kernel (development aid).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip -o tools/gemm_bench
+// Run:   tools/gemm_bench [layer]      (layer: 1..6 conv, 7 classifier GEMM, 8 lstm ih)
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvGemm {
+  const float* A; const float* Wt; const float* bias; float* C; const int* wvalid; const float* zero;
+  int M, N, K, ldc; int Hin, Win, Cin, Hout, Wout, ks, pad; int act;
+};
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Variant V: BK_, NBUF (LDS buffers), PRIO (0 none, 1 setprio(1) around MFMA, 2 setprio(1) outside MFMA),
+// MINB = min blocks per CU hint (waves per SIMD)
+// ---------------------------------------------------------------------------------------------
+template <int BK_, int NBUF, int PRIO, int MINW, int KORD = 0, int ABL = 0>
+__global__ __launch_bounds__(256, MINW) void gemm_v(const ConvGemm p) {
+  constexpr int BM = 128, BN = 128, LDT = BK_ + 4;
+  constexpr int KG = BK_ / 8;               // k-groups per tile
+  constexpr int TPR = BK_ / 4;              // threads per row (float4 each)
+  constexpr int RPP = 256 / TPR;            // rows per pass
+  constexpr int NP = BM / RPP;              // passes
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int bm = blockIdx.x / ntn, bn = blockIdx.x - bm * ntn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int lrow = tid / TPR;
+  const int lk = (tid % TPR) * 4;
+  const int hw = p.Hout * p.Wout;
+  const float* arow[NP]; unsigned amask[NP]; const float* brow[NP];
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
+    int m = m0 + lrow + RPP * i;
+    m = m < p.M ? m : p.M - 1;
+    const int b = m / hw, r = m - b * hw;
+    const int y = r / p.Wout, x = r - y * p.Wout;
+    arow[i] = p.A + (((long)b * p.Hin + (y - p.pad)) * p.Win + (x - p.pad)) * p.Cin + lk;
+    unsigned mk = 0;
+    for (int ky = 0; ky < p.ks; ky++)
+      for (int kx = 0; kx < p.ks; kx++) {
+        const int yy = y - p.pad + ky, xx = x - p.pad + kx;
+        if ((unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win) mk |= 1u << (ky * p.ks + kx);
+      }
+    amask[i] = mk;
+    int n = n0 + lrow + RPP * i;
+    n = n < p.N ? n : p.N - 1;
+    brow[i] = p.Wt + (long)n * p.K + lk;
+  }
+  const int nk = p.K / BK_;
+  f32x4 ra[NP], rb[NP];
+  int l_tap = 0, l_ky = 0, l_kx = 0, l_ci = 0, l_k0 = 0;
+  auto gload = [&]() {
+    const long toff = ((long)l_ky * p.Win + l_kx) * p.Cin + l_ci;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const float* src = ((amask[i] >> l_tap) & 1u) ? arow[i] + toff : p.zero;
+      if (ABL == 6) src = ((amask[i] >> l_tap) & 1u) ? p.A + lk + (i * 64 + (toff & 63)) * 4 : p.zero;   // same instructions, tiny footprint
+      ra[i] = *(const f32x4*)src;
+      rb[i] = *(const f32x4*)(brow[i] + (ABL == 6 ? (l_k0 & 63) : l_k0));
+    }
+    l_k0 += BK_;
+    if (KORD == 0) {
+      l_ci += BK_;
+      const bool wrap_c = l_ci == p.Cin;
+      l_ci = wrap_c ? 0 : l_ci; l_tap += wrap_c ? 1 : 0; l_kx += wrap_c ? 1 : 0;
+      const bool wrap_x = l_kx == p.ks;
+      l_kx = wrap_x ? 0 : l_kx; l_ky += wrap_x ? 1 : 0;
+    } else {
+      l_tap++; l_kx++;
+      const bool wrap_x = l_kx == p.ks;
+      l_kx = wrap_x ? 0 : l_kx; l_ky += wrap_x ? 1 : 0;
+      const bool wrap_t = l_ky == p.ks;
+      l_ky = wrap_t ? 0 : l_ky; l_tap = wrap_t ? 0 : l_tap; l_ci += wrap_t ? BK_ : 0;
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* sa = smem + buf * (BM + BN) * LDT;
+    float* sb = sa + BM * LDT;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      *(f32x4*)(sa + (lrow + RPP * i) * LDT + lk) = ra[i];
+      *(f32x4*)(sb + (lrow + RPP * i) * LDT + lk) = rb[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  auto compute = [&](int cur) {
+    const float* a = smem + cur * (BM + BN) * LDT + (wm * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
+    const float* b = smem + cur * (BM + BN) * LDT + BM * LDT + (wn * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) {
+      f32x4 a0 = *(const f32x4*)(a + kg * 8);
+      f32x4 a1 = *(const f32x4*)(a + 32 * LDT + kg * 8);
+      f32x4 b0 = *(const f32x4*)(b + kg * 8);
+      f32x4 b1 = *(const f32x4*)(b + 32 * LDT + kg * 8);
+      if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+      if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+      }
+      if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+      if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
+    }
+  };
+  if (NBUF == 2) {
+    gload(); sstore(0); __syncthreads();
+    for (int kt = 0; kt < nk - 1; kt++) {
+      const int cur = (ABL >= 1 && ABL <= 3) ? 0 : (kt & 1);
+      if (ABL == 0 || ABL == 3 || ABL >= 4) gload();
+      if (ABL == 4) __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      if (ABL == 5) {
+        // pin: the 8 loads (and their address VALU) are spread over the first MFMAs of the tile
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // up to 8 VALU
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        }
+      }
+      if (ABL == 0 || ABL >= 4) sstore(cur ^ 1);
+      if (ABL == 3) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) asm volatile("" :: "v"(ra[i]), "v"(rb[i]));
+      }
+      if (ABL != 2) __syncthreads();
+    }
+    compute((ABL >= 1 && ABL <= 3) ? 0 : ((nk - 1) & 1));
+  } else {
+    gload(); sstore(0); __syncthreads();
+    for (int kt = 0; kt < nk - 1; kt++) {
+      gload(); compute(0); __syncthreads(); sstore(0); __syncthreads();
+    }
+    compute(0);
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
+    const bool nok = n < p.N;
+    const float bias = nok ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[mt][nt][r] + bias;
+        if (p.act == 1) v = v > 0.f ? v : 0.f;
+        if (row < p.M && nok) p.C[(long)row * p.ldc + n] = v;
+      }
+  }
+}
+
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// Variant B: raw buffer loads.  voffset per lane is constant over the K loop (pixel / weight row
+// base, or 0x80000000-range OOB for padding taps via a per-tap select); the K position goes in
+// the scalar offset, so the loader needs ~1 VALU per load.
+template <int NBUF, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
+  constexpr int BK_ = 32, BM = 128, BN = 128, LDT = BK_ + 4, KG = 4, NP = 4;
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int bm = blockIdx.x / ntn, bn = blockIdx.x - bm * ntn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int lrow = tid >> 3, lk = (tid & 7) * 4;
+  const int hw = p.Hout * p.Wout;
+  // descriptor bases: A shifted back by the padding so that every voffset is >= 0
+  const long shift = ((long)p.pad * p.Win + p.pad) * p.Cin;
+  const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A - shift), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, 0x7FFFFFFF, 0x00020000);
+  unsigned aoff[NP], amask[NP], boff[NP];
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
+    int m = m0 + lrow + 32 * i;
+    m = m < p.M ? m : p.M - 1;
+    const int b = m / hw, r = m - b * hw;
+    const int y = r / p.Wout, x = r - y * p.Wout;
+    aoff[i] = (unsigned)(((((long)b * p.Hin + y) * p.Win + x) * p.Cin + lk) * 4);
+    unsigned mk = 0;
+    for (int ky = 0; ky < p.ks; ky++)
+      for (int kx = 0; kx < p.ks; kx++) {
+        const int yy = y - p.pad + ky, xx = x - p.pad + kx;
+        if ((unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win) mk |= 1u << (ky * p.ks + kx);
+      }
+    amask[i] = mk;
+    int n = n0 + lrow + 32 * i;
+    n = n < p.N ? n : p.N - 1;
+    boff[i] = (unsigned)(((long)n * p.K + lk) * 4);
+  }
+  const int nk = p.K / BK_;
+  f32x4 ra[NP], rb[NP];
+  int l_tap = 0, l_ky = 0, l_kx = 0, l_ci = 0, l_k0 = 0;
+  auto gload = [&]() {
+    const int toff = ((l_ky * p.Win + l_kx) * p.Cin + l_ci) * 4;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const unsigned vo = ((amask[i] >> l_tap) & 1u) ? aoff[i] : 0x80000000u;   // OOB -> zeros
+      i32x4 va = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, vo, toff, 0);
+      i32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, boff[i], l_k0 * 4, 0);
+      ra[i] = __builtin_bit_cast(f32x4, va);
+      rb[i] = __builtin_bit_cast(f32x4, vb);
+    }
+    l_k0 += BK_; l_ci += BK_;
+    const bool wrap_c = l_ci == p.Cin;
+    l_ci = wrap_c ? 0 : l_ci; l_tap += wrap_c ? 1 : 0; l_kx += wrap_c ? 1 : 0;
+    const bool wrap_x = l_kx == p.ks;
+    l_kx = wrap_x ? 0 : l_kx; l_ky += wrap_x ? 1 : 0;
+  };
+  auto sstore = [&](int buf) {
+    float* sa = smem + buf * (BM + BN) * LDT;
+    float* sb = sa + BM * LDT;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      *(f32x4*)(sa + (lrow + 32 * i) * LDT + lk) = ra[i];
+      *(f32x4*)(sb + (lrow + 32 * i) * LDT + lk) = rb[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  auto compute = [&](int cur) {
+    const float* a = smem + cur * (BM + BN) * LDT + (wm * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
+    const float* b = smem + cur * (BM + BN) * LDT + BM * LDT + (wn * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
+#pragma unroll
+    for (int kg = 0; kg < KG; kg++) {
+      f32x4 a0 = *(const f32x4*)(a + kg * 8);
+      f32x4 a1 = *(const f32x4*)(a + 32 * LDT + kg * 8);
+      f32x4 b0 = *(const f32x4*)(b + kg * 8);
+      f32x4 b1 = *(const f32x4*)(b + 32 * LDT + kg * 8);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+      }
+    }
+  };
+  if (NBUF == 2) {
+    gload(); sstore(0); __syncthreads();
+    for (int kt = 0; kt < nk - 1; kt++) {
+      const int cur = kt & 1;
+      gload(); compute(cur); sstore(cur ^ 1); __syncthreads();
+    }
+    compute((nk - 1) & 1);
+  } else {
+    gload(); sstore(0); __syncthreads();
+    for (int kt = 0; kt < nk - 1; kt++) {
+      gload(); compute(0); __syncthreads(); sstore(0); __syncthreads();
+    }
+    compute(0);
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
+    const bool nok = n < p.N;
+    const float bias = nok ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[mt][nt][r] + bias;
+        if (p.act == 1) v = v > 0.f ? v : 0.f;
+        if (row < p.M && nok) p.C[(long)row * p.ldc + n] = v;
+      }
+  }
+}
+
+template <typename F>
+float time_kernel(F launch, int iters) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; i++) launch();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; i++) launch();
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters;
+}
+
+int main(int argc, char** argv) {
+  int layer = argc > 1 ? atoi(argv[1]) : 5;
+  const int B = 256;
+  ConvGemm p{};
+  // geometry at W=280: W1=140 W2=70 W3=71 W4=72 T=71
+  switch (layer) {
+    case 1: p.Hin = 16; p.Win = 140; p.Cin = 64;  p.Hout = 16; p.Wout = 140; p.N = 128; p.ks = 3; p.pad = 1; break;
+    case 2: p.Hin = 8;  p.Win = 70;  p.Cin = 128; p.Hout = 8;  p.Wout = 70;  p.N = 256; p.ks = 3; p.pad = 1; break;
+    case 3: p.Hin = 8;  p.Win = 70;  p.Cin = 256; p.Hout = 8;  p.Wout = 70;  p.N = 256; p.ks = 3; p.pad = 1; break;
+    case 4: p.Hin = 4;  p.Win = 71;  p.Cin = 256; p.Hout = 4;  p.Wout = 71;  p.N = 512; p.ks = 3; p.pad = 1; break;
+    case 5: p.Hin = 4;  p.Win = 71;  p.Cin = 512; p.Hout = 4;  p.Wout = 71;  p.N = 512; p.ks = 3; p.pad = 1; break;
+    case 6: p.Hin = 2;  p.Win = 72;  p.Cin = 512; p.Hout = 1;  p.Wout = 71;  p.N = 512; p.ks = 2; p.pad = 0; break;
+    case 7: p.Hin = 1;  p.Win = 1;   p.Cin = 512; p.Hout = 1;  p.Wout = 1;   p.N = 5530; p.ks = 1; p.pad = 0; break;
+    default: p.Hin = 1; p.Win = 1;   p.Cin = 512; p.Hout = 1;  p.Wout = 1;   p.N = 2048; p.ks = 1; p.pad = 0; break;
+  }
+  const long nb = (layer >= 7) ? (long)B * 71 : B;
+  p.M = (int)(nb * p.Hout * p.Wout); p.K = p.ks * p.ks * p.Cin; p.ldc = p.N; p.act = 1;
+  const size_t na = (size_t)nb * p.Hin * p.Win * p.Cin, nw = (size_t)p.N * p.K, nc = (size_t)p.M * p.N;
+  std::vector<float> hA(na), hW(nw), hb(p.N);
+  unsigned s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+  for (auto& v : hA) v = rnd();
+  for (auto& v : hW) v = rnd() * 0.1f;
+  for (auto& v : hb) v = rnd();
+  float *dA, *dW, *db, *dC, *dz;
+  CK(hipMalloc(&dA, na * 4)); CK(hipMalloc(&dW, nw * 4)); CK(hipMalloc(&db, p.N * 4)); CK(hipMalloc(&dC, nc * 4));
+  CK(hipMalloc(&dz, 256)); CK(hipMemset(dz, 0, 256));
+  CK(hipMemcpy(dA, hA.data(), na * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dW, hW.data(), nw * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, hb.data(), p.N * 4, hipMemcpyHostToDevice));
+  p.A = dA; p.Wt = dW; p.bias = db; p.C = dC; p.zero = dz; p.wvalid = nullptr;
+  const double flop = 2.0 * p.M * p.N * p.K;
+  const int grid = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+  printf("layer %d: M=%d N=%d K=%d grid=%d  %.1f GFLOP\n", layer, p.M, p.N, p.K, grid, flop / 1e9);
+  std::vector<float> hC(nc);
+  int kord = 0;
+  auto check = [&](const char* name) {
+    CK(hipMemcpy(hC.data(), dC, nc * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int t = 0; t < 64; t++) {
+      const int m = (int)(((long)t * 7919 * 131) % p.M), n = (t * 977) % p.N;
+      const int hwo = p.Hout * p.Wout; const int b = m / hwo, r = m % hwo, y = r / p.Wout, x = r % p.Wout;
+      double acc = hb[n];
+      for (int ky = 0; ky < p.ks; ky++) for (int kx = 0; kx < p.ks; kx++) {
+        const int yy = y - p.pad + ky, xx = x - p.pad + kx;
+        if (yy < 0 || yy >= p.Hin || xx < 0 || xx >= p.Win) continue;
+        for (int c = 0; c < p.Cin; c++)
+          acc += (double)hA[(((size_t)b * p.Hin + yy) * p.Win + xx) * p.Cin + c] * hW[(size_t)n * p.K + (kord ? ((c / 32) * p.ks * p.ks + ky * p.ks + kx) * 32 + c % 32 : (ky * p.ks + kx) * p.Cin + c)];
+      }
+      if (acc < 0) acc = 0;
+      maxerr = fmax(maxerr, fabs(acc - hC[(size_t)m * p.N + n]));
+    }
+    printf("  %-28s maxerr %.2e\n", name, maxerr);
+  };
+#define RUN(NAME, ...)                                                                         \
+  do {                                                                                         \
+    CK(hipMemset(dC, 0, nc * 4));                                                              \
+    float ms = time_kernel([&]() { hipLaunchKernelGGL((gemm_v<__VA_ARGS__>), dim3(grid), dim3(256), 0, 0, p); }, 20); \
+    CK(hipGetLastError());                                                                     \
+    printf("%-30s %.4f ms  %.1f TF/s\n", NAME, ms, flop / ms / 1e9);                          \
+    check(NAME);                                                                               \
+  } while (0)
+#define RUNB(NAME, ...)                                                                        \
+  do {                                                                                         \
+    CK(hipMemset(dC, 0, nc * 4));                                                              \
+    float ms = time_kernel([&]() { hipLaunchKernelGGL((gemm_b<__VA_ARGS__>), dim3(grid), dim3(256), 0, 0, p); }, 20); \
+    CK(hipGetLastError());                                                                     \
+    printf("%-30s %.4f ms  %.1f TF/s\n", NAME, ms, flop / ms / 1e9);                          \
+    check(NAME);                                                                               \
+  } while (0)
+  for (int rep = 0; rep < 2; rep++) {
+    kord = 0;
+    RUN("bk32 nbuf2 (current)", 32, 2, 0, 2);
+    RUN("bk32 nbuf1 minw3", 32, 1, 0, 3);
+    RUNB("buffer loads nbuf2", 2, 2);
+    RUNB("buffer loads nbuf1 minw3", 1, 3);
+  }
+  return 0;
+}
