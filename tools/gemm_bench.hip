@@ -380,8 +380,22 @@ int main(int argc, char** argv) {
     kord = 0;
     RUN("bk32 nbuf2 (current)", 32, 2, 0, 2);
     RUN("bk32 nbuf1 minw3", 32, 1, 0, 3);
-    RUNB("buffer loads nbuf2", 2, 2);
     RUNB("buffer loads nbuf1 minw3", 1, 3);
+    for (int ns = 2; ns <= 3; ns++) {
+      hipStream_t st[3];
+      for (int i = 0; i < ns; i++) CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+      int k = 0;
+      float ms = time_kernel([&]() { hipLaunchKernelGGL((gemm_b<1, 3>), dim3(grid), dim3(256), 0, st[k++ % ns], p); }, 30);
+      // time_kernel's events are on the null stream: re-time with explicit syncs
+      CK(hipDeviceSynchronize());
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      CK(hipEventRecord(e0, st[0]));
+      for (int i = 0; i < 30; i++) hipLaunchKernelGGL((gemm_b<1, 3>), dim3(grid), dim3(256), 0, st[i % ns], p);
+      for (int i = 1; i < ns; i++) { hipEvent_t e; CK(hipEventCreate(&e)); CK(hipEventRecord(e, st[i])); CK(hipStreamWaitEvent(st[0], e, 0)); }
+      CK(hipEventRecord(e1, st[0])); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 30;
+      printf("%d streams, buffer nbuf1        %.4f ms  %.1f TF/s\n", ns, ms, flop / ms / 1e9);
+    }
   }
   return 0;
 }
