@@ -43,6 +43,7 @@ class CRNN(object):
         if imgH != 32 or nc != 1 or nh != 256:
             raise ValueError("the HIP path implements the shipped configuration: imgH=32, nc=1, nh=256")
         self.lstmFlag = lstmFlag
+        self.leakyRelu = bool(leakyRelu)
         self.GPU = GPU
         self.alphabet = alphabet
         self.nclass = nclass
@@ -130,13 +131,11 @@ class CRNN(object):
         if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8 or a.size == 0:
             # cv2.cvtColor(image, COLOR_BGR2RGB) raises on anything else (:124)
             raise ValueError("CRNN.ocr expects a non-empty HxWx3 uint8 BGR array, got %s %s" % (a.dtype, a.shape))
-        lab, ln, _, _, _ = self._run([a], _capi.PAD_PER_LINE)
-        return self._texts(lab, ln)[0]
+        return self.predict_lines([a])[0]
 
     def predict(self, image):
         """network_torch.py:130-147: PIL 'L' image -> text ('' when the resized width is < 8)."""
-        lab, ln, _, _, _ = self._run([_as_gray_array(image)], _capi.PAD_PER_LINE)
-        return self._texts(lab, ln)[0]
+        return self.predict_lines([_as_gray_array(image)])[0]
 
     def predict_job(self, boxes):
         """network_torch.py:149-155: per-box predict; results are what predict gives each box alone."""
@@ -178,8 +177,24 @@ class CRNN(object):
                 raise ZeroDivisionError("float division by zero")
             widths.append(_capi.check(self._h, self._lib.crnn_resized_width(self._h, a.shape[1], a.shape[0])))
         out = [None] * len(arrs)
+        pad_mode = _capi.PAD_PER_LINE
+        if self.leakyRelu:
+            # Per-line width masks rely on post-ReLU zeros standing in for the -inf pooling pad;
+            # with LeakyReLU activations can be negative, so only lines of IDENTICAL width share a
+            # batch (then no mask is needed and the result is exact).
+            width_spread = 1.0
+            narrow = [i for i, w in enumerate(widths) if w < 8]
+            for i in narrow:
+                out[i] = ''
+            keep = [i for i, w in enumerate(widths) if w >= 8]
+            arrs_k, widths_k = [arrs[i] for i in keep], [widths[i] for i in keep]
+            for bucket in width_buckets(widths_k, max_batch, 1.0):
+                lab, ln, _, _, _ = self._run([arrs_k[i] for i in bucket], _capi.PAD_REFERENCE)
+                for i, t in zip(bucket, self._texts(lab, ln)):
+                    out[keep[i]] = t
+            return out
         for bucket in width_buckets(widths, max_batch, width_spread):
-            lab, ln, _, _, _ = self._run([arrs[i] for i in bucket], _capi.PAD_PER_LINE)
+            lab, ln, _, _, _ = self._run([arrs[i] for i in bucket], pad_mode)
             for i, t in zip(bucket, self._texts(lab, ln)):
                 out[i] = t
         return out

@@ -1,0 +1,55 @@
+"""Batched CRNN branch for the reference's OCR context.
+
+`obj_det/ocr_context.py` `TextOcrModel.batch_ocr(images, use_paddle_first=False)` loops the
+CRNN one crop at a time (`ocr_context.py:302-310`), and `_ocr` calls
+`self._chinese_ocr_instance(img)` for single crops (`:119,:123,:139`).  This adapter keeps those
+call shapes and their error conventions ("" for a None image or any per-image failure) but runs
+the crops as width-bucketed device batches through `CRNN.predict_lines`.
+
+Usage inside the reference (one line in TextOcrModel.__init__ / batch_ocr):
+    self._crnn_batch = CrnnOcrContext(settings.crnn)
+    ...
+    else:   # use_paddle_first == False
+        return self._crnn_batch.batch_ocr(images)
+"""
+import numpy as np
+
+
+class CrnnOcrContext(object):
+    def __init__(self, crnn, max_batch=256):
+        self.crnn = crnn
+        self.max_batch = max_batch
+        self._chinese_ocr_instance = crnn.ocr   # same attribute name as TextOcrModel (:28)
+
+    def ocr(self, img):
+        """Single BGR crop -> text; "" on any failure (the try/except of ocr_context.py:133-144)."""
+        try:
+            return self.crnn.ocr(img) if img is not None else ""
+        except Exception:
+            return ""
+
+    @staticmethod
+    def _usable(img):
+        if img is None:
+            return False
+        a = np.asarray(img)
+        return a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3 and a.size > 0
+
+    def batch_ocr(self, images, use_paddle_first=False, batch_size=None):
+        """List of BGR crops -> list of texts, position by position (ocr_context.py:271-314, CRNN branch)."""
+        if not images:
+            return []
+        results = [""] * len(images)
+        good = [i for i, im in enumerate(images) if self._usable(im)]
+        if not good:
+            return results
+        try:
+            texts = self.crnn.predict_lines([images[i] for i in good],
+                                            max_batch=batch_size or self.max_batch)
+            for i, t in zip(good, texts):
+                results[i] = t
+        except Exception:
+            # one bad crop (e.g. resized width 0) must not lose the others: isolate per image
+            for i in good:
+                results[i] = self.ocr(images[i])
+        return results

@@ -207,6 +207,21 @@ def main():
     arrays["edge/w8/gray"] = w8
     meta["edge_w8"] = zh.predict(Image.fromarray(w8, mode="L"))
 
+    # ---- constructor variants (network_torch.py:60-64 leakyRelu, :85-86/:102-106 lstmFlag=False)
+    dense = build_ref(65, ref_keys.alphabetEnglish, lstm=False)
+    leaky = build_ref(65, ref_keys.alphabetEnglish, lstm=True, leaky=True)
+    vnames = ["tax", "invoice_number", "seal_1"]
+    meta["variants"] = {"names": vnames, "dense": [], "leaky": []}
+    for n in vnames:
+        g = arrays["inv/%s/gray" % n]
+        for tag, mdl in (("dense", dense), ("leaky", leaky)):
+            _, lgv = ref_logits(mdl, g)
+            arrays["variants/%s/%s/logits" % (tag, n)] = lgv.astype(np.float32)
+            meta["variants"][tag].append(mdl.predict(Image.fromarray(g, mode="L")))
+    boxes = [{"img": Image.fromarray(arrays["inv/%s/gray" % n], mode="L")} for n in vnames]
+    with torch.no_grad():
+        meta["variants"]["leaky_predict_batch"] = [b["text"] for b in leaky.predict_batch(boxes, batch_size=3)]
+
     np.savez_compressed(os.path.join(HERE, "crnn_golden.npz"), **arrays)
     with open(os.path.join(HERE, "crnn_golden.json"), "w", encoding="utf-8") as f:
         json.dump(meta, f, ensure_ascii=False, indent=1)

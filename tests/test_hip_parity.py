@@ -163,3 +163,40 @@ def test_synthetic_280_and_variable_width(golden, hip_zh, hip_en):
     for i, w in enumerate(M["var_widths"]):
         assert tt[i] == w // 4 + 1
         assert np.abs(logits[i, :tt[i]] - G["var/%d/en_logits" % w]).max() < LOGIT_TOL, w
+
+
+def test_constructor_variants(golden):
+    """lstmFlag=False and leakyRelu=True (network_torch.py:60-64, :85-86, :102-106)."""
+    from PIL import Image
+    from ocr_amd.crnn.network_hip import CRNN
+    from ocr_amd.crnn.synth import synth_state_dict
+    G, M = golden
+    V = M["variants"]
+    dense = CRNN(32, 1, 65, 256, leakyRelu=False, lstmFlag=False, GPU=True, alphabet=keys.alphabetEnglish)
+    dense.load_state_dict(synth_state_dict(65, seed=0, lstm=False))
+    leaky = CRNN(32, 1, 65, 256, leakyRelu=True, lstmFlag=True, GPU=True, alphabet=keys.alphabetEnglish)
+    leaky.load_state_dict(synth_state_dict(65, seed=0))
+    imgs = [G["inv/%s/gray" % n] for n in V["names"]]
+    for tag, m in (("dense", dense), ("leaky", leaky)):
+        for i, n in enumerate(V["names"]):
+            raw, tt, logits, _, _ = m.forward_logits([imgs[i]], pad_mode=1)
+            assert np.abs(logits[0, :tt[0]] - G["variants/%s/%s/logits" % (tag, n)]).max() < LOGIT_TOL, (tag, n)
+            assert m.predict(Image.fromarray(imgs[i], mode="L")) == V[tag][i], (tag, n)
+        assert m.predict_lines(imgs) == V[tag], tag     # mixed widths in one call stay exact
+    boxes = [{"img": Image.fromarray(im, mode="L")} for im in imgs]
+    assert [b["text"] for b in leaky.predict_batch(boxes, batch_size=3)] == V["leaky_predict_batch"]
+
+
+def test_ocr_context_adapter(golden, hip_zh):
+    """Batched CRNN branch for TextOcrModel.batch_ocr (ocr_context.py:302-310): same texts as one
+    crop at a time, "" for None / unusable crops."""
+    from ocr_amd.ocr_context import CrnnOcrContext
+    G, M = golden
+    ctx = CrnnOcrContext(hip_zh)
+    crops = [G["inv/%s/bgr" % it["name"]] for it in M["invoice"]]
+    images = crops[:5] + [None, np.zeros((0, 0, 3), np.uint8), np.zeros((90, 2, 3), np.uint8)] + crops[5:]
+    want = [it["zh"] for it in M["invoice"]]
+    want = want[:5] + ["", "", ""] + want[5:]
+    assert ctx.batch_ocr(images) == want
+    assert ctx.batch_ocr([]) == []
+    assert ctx.ocr(crops[0]) == want[0] and ctx.ocr(None) == "" and ctx._chinese_ocr_instance(crops[1]) == want[1]

@@ -128,3 +128,18 @@ def test_ctc_collapse_rules():
     lg = np.zeros((1, 1, 7), np.float32)
     lg[0, 0, [2, 5]] = 1.0
     assert O.argmax(lg)[0, 0] == 2
+
+
+def test_constructor_variants(golden):
+    """lstmFlag=False (dense head) and leakyRelu=True against the reference's outputs."""
+    from ocr_amd.crnn.synth import synth_state_dict
+    G, M = golden
+    V = M["variants"]
+    dense = O.Oracle(synth_state_dict(65, seed=0, lstm=False), 65, lstm=False)
+    leaky = O.Oracle(synth_state_dict(65, seed=0), 65, leaky=True)
+    for i, n in enumerate(V["names"]):
+        x = O.resize_normalize(G["inv/%s/gray" % n])
+        for tag, orc in (("dense", dense), ("leaky", leaky)):
+            lg = orc.forward(x[None])
+            assert np.abs(lg[:, 0] - G["variants/%s/%s/logits" % (tag, n)]).max() < LOGIT_TOL, (tag, n)
+            assert O.decode(O.argmax(lg)[0], keys.alphabetEnglish) == V[tag][i], (tag, n)
