@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 BATCH, WIDTH, NCLASS = 256, 280, 5530
 FLOP_PER_LINE = 4283.46e6          # 2*MACs per 32x280 line, nclass 5530
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32 MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -61,6 +62,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--lanes", type=int, default=3, help="independent stream/workspace lanes per GPU")
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32 = the headline, parity-exact path; bf16 = bf16 MFMA inputs, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,7 +90,7 @@ def main():
 
     sd = synth_state_dict(NCLASS, seed=0)
     model = CRNN(32, 1, NCLASS, 256, leakyRelu=False, lstmFlag=True, GPU=True, alphabet=keys.alphabetChinese,
-                 device=local_rank, lanes=args.lanes)
+                 device=local_rank, lanes=args.lanes, precision=args.precision)
     model.load_state_dict(sd)
     NL = model.lanes
 
@@ -170,6 +173,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     lines_total = BATCH * args.steps * world
     value = lines_total / elapsed
     gemm_names = [n for n in order if n.startswith("conv") and n != "conv0_pool0" or n in
@@ -184,22 +188,23 @@ def main():
         "metric": "text-lines/sec at 32x280 crops (CRNN ocr-lstm head, 5530 classes)",
         "value": round(value, 1), "unit": "text-lines/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "bf16",
         "data": "synthetic (seeded uniform uint8 lines, seeded synthetic weights)",
-        "config": {"workload": "configs[1]: CRNN fp32, batch 256 synthetic 32x280 grayscale lines per step per GPU, "
-                               "uint8 lines resident in HBM -> decoded strings on the host",
+        "config": {"workload": "configs[1]: CRNN %s, batch 256 synthetic 32x280 grayscale lines per step per GPU, "
+                               "uint8 lines resident in HBM -> decoded strings on the host" % args.precision,
                    "batch": BATCH, "width": WIDTH, "nclass": NCLASS, "lines_per_step": BATCH * world,
                    "lanes_per_gpu": NL,
                    "sharding": "independent lines, one replica per GPU, no collective"},
         "roofline": {
-            "bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv1-6 + LSTM input projections + "
+            "bound": "mfma", "kernel": ("conv_gemm_kernel" if args.precision == "fp32" else "conv_gemm_bf16_kernel") + " (implicit-GEMM conv1-6 + LSTM input projections + "
                                        "embedding + classifier, %d launches per step)" % len(gemm_names),
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
             "flops_per_launch_avg": g_fl / max(1, len(gemm_names)),
             "ms_per_launch_avg": round(g_ms / max(1, len(gemm_names)), 4)},
         "pipeline_tflops": round(FLOP_PER_LINE * value / 1e12, 2),
-        "pipeline_frac_of_f32_mfma_peak": round(FLOP_PER_LINE * value / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+        "pipeline_frac_of_mfma_peak": round(FLOP_PER_LINE * value / 1e12 / (peak * world), 4),
         "kernels": kernels,
     }
     if not args.no_cpu_baseline:

@@ -39,6 +39,9 @@ typedef enum {
   CRNN_ERR_NOMEM = -6
 } crnn_status;
 
+#define CRNN_FP32 0
+#define CRNN_BF16 1
+
 /* Constructor arguments of CRNN(imgH, nc, nclass, nh, leakyRelu, lstmFlag, GPU, alphabet)
  * -- crnn/network_torch.py:37; built at settings.py:45 as CRNN(32,1,nclass,256,False,LSTMFLAG,GPU,alphabet). */
 typedef struct {
@@ -50,6 +53,9 @@ typedef struct {
   int32_t lstm;       /* lstmFlag */
   int32_t device;     /* HIP device ordinal (config.GPUID) */
   int32_t lanes;      /* independent (stream, workspace) lanes crnn_forward_device rotates over; 0 -> 1, max 4 */
+  int32_t precision;  /* CRNN_FP32 (exact fp32 MFMA; the parity path) or CRNN_BF16 (bf16 MFMA inputs, fp32
+                         accumulate; reports character agreement, not held to the 1e-3 logit bound) */
+  int32_t reserved;
 } crnn_config;
 
 /* One entry of the flat state dict CRNN.load_weights reads (network_torch.py:110-117):

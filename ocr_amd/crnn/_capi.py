@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG, "libcrnn_hip.so")
 CRNN_OK = 0
 CRNN_ERR_ARG, CRNN_ERR_HIP, CRNN_ERR_STATE, CRNN_ERR_ZERO_H, CRNN_ERR_ZERO_W, CRNN_ERR_NOMEM = -1, -2, -3, -4, -5, -6
 PAD_PER_LINE, PAD_REFERENCE = 0, 1
+FP32, BF16 = 0, 1
 
 SYMBOLS = ["crnn_create", "crnn_load_weights", "crnn_resized_width", "crnn_out_len", "crnn_preprocess",
            "crnn_predict_batch", "crnn_forward_device", "crnn_debug_stage", "crnn_synchronize", "crnn_stream", "crnn_lanes",
@@ -22,7 +23,8 @@ SYMBOLS = ["crnn_create", "crnn_load_weights", "crnn_resized_width", "crnn_out_l
 
 class Config(C.Structure):
     _fields_ = [("img_h", C.c_int32), ("nc", C.c_int32), ("nclass", C.c_int32), ("nh", C.c_int32),
-                ("leaky_relu", C.c_int32), ("lstm", C.c_int32), ("device", C.c_int32), ("lanes", C.c_int32)]
+                ("leaky_relu", C.c_int32), ("lstm", C.c_int32), ("device", C.c_int32), ("lanes", C.c_int32),
+                ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Tensor(C.Structure):

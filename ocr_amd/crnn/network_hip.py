@@ -38,7 +38,7 @@ class CRNN(object):
     """Same surface as ``crnn.network_torch.CRNN``; inference only."""
 
     def __init__(self, imgH, nc, nclass, nh, leakyRelu=False, lstmFlag=True, GPU=False, alphabet=None, device=None,
-                 lanes=1):
+                 lanes=1, precision='fp32'):
         assert imgH % 16 == 0, 'imgH has to be a multiple of 16'
         if imgH != 32 or nc != 1 or nh != 256:
             raise ValueError("the HIP path implements the shipped configuration: imgH=32, nc=1, nh=256")
@@ -47,11 +47,13 @@ class CRNN(object):
         self.GPU = GPU
         self.alphabet = alphabet
         self.nclass = nclass
+        self.precision = precision
         if device is None:
             device = int(os.environ.get("CRNN_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         self.device = device
         self._lib = _capi.lib()
-        cfg = _capi.Config(imgH, nc, nclass, nh, int(bool(leakyRelu)), int(bool(lstmFlag)), device, lanes)
+        cfg = _capi.Config(imgH, nc, nclass, nh, int(bool(leakyRelu)), int(bool(lstmFlag)), device, lanes,
+                           {'fp32': _capi.FP32, 'bf16': _capi.BF16}[precision], 0)
         h = C.c_void_p()
         rc = self._lib.crnn_create(C.byref(cfg), C.byref(h))
         if rc != 0:

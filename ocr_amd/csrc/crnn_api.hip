@@ -67,6 +67,8 @@ struct crnn_handle {
   std::vector<float> h_conv_w[7], h_conv_b[7];
   std::vector<float> h_wih[2], h_bih[2], h_whhp[2], h_emb_w[2], h_emb_b[2], h_lin_w, h_lin_b;
   float lut[256];
+  // bf16 copies (precision == CRNN_BF16): conv1..6, W_ih, embeddings / linear, packed W_hh
+  std::vector<uint16_t> hb_conv_w[7], hb_wih[2], hb_whhp[2], hb_emb_w[2], hb_lin_w;
 
   // device state
   pid_t dev_pid = 0;
@@ -81,6 +83,11 @@ struct crnn_handle {
   float* d_emb_b[2] = {};
   float* d_lin_w = nullptr;
   float* d_lin_b = nullptr;
+  uint16_t* db_conv_w[7] = {};
+  uint16_t* db_wih[2] = {};
+  uint16_t* db_whhp[2] = {};
+  uint16_t* db_emb_w[2] = {};
+  uint16_t* db_lin_w = nullptr;
   bool kprof = false;
 
   // Lanes: independent (stream, workspace) pairs.  Successive crnn_forward_device calls go to
@@ -125,6 +132,13 @@ int upload(crnn_handle* h, const std::vector<float>& src, float** dst) {
   if (src.empty()) { *dst = nullptr; return 0; }
   HIPCHK(h, hipMalloc((void**)dst, src.size() * sizeof(float)));
   HIPCHK(h, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int upload16(crnn_handle* h, const std::vector<uint16_t>& src, uint16_t** dst) {
+  if (src.empty()) { *dst = nullptr; return 0; }
+  HIPCHK(h, hipMalloc((void**)dst, src.size() * sizeof(uint16_t)));
+  HIPCHK(h, hipMemcpy(*dst, src.data(), src.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -179,6 +193,14 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     }
     if ((rc = upload(h, h->h_lin_w, &h->d_lin_w))) return rc;
     if ((rc = upload(h, h->h_lin_b, &h->d_lin_b))) return rc;
+    for (int i = 0; i < 7; i++)
+      if ((rc = upload16(h, h->hb_conv_w[i], &h->db_conv_w[i]))) return rc;
+    for (int l = 0; l < 2; l++) {
+      if ((rc = upload16(h, h->hb_wih[l], &h->db_wih[l]))) return rc;
+      if ((rc = upload16(h, h->hb_whhp[l], &h->db_whhp[l]))) return rc;
+      if ((rc = upload16(h, h->hb_emb_w[l], &h->db_emb_w[l]))) return rc;
+    }
+    if ((rc = upload16(h, h->hb_lin_w, &h->db_lin_w))) return rc;
     h->weights_on_dev = true;
   }
   return 0;
@@ -292,28 +314,36 @@ void kmark(crnn_handle* h, const char* name, double flop, double bytes) {
   (void)hipEventRecord(h->cur->kev[h->cur->nk], h->cur->stream);
 }
 
-void gemm(crnn_handle* h, const char* name, const float* A, const float* Wt, const float* bias, float* C, int M,
-          int N, int K) {
+// out_bf16 only matters on the bf16 path (which GEMM outputs feed another GEMM)
+void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, const uint16_t* Wt16,
+          const float* bias, void* C, int M, int N, int K, bool out_bf16) {
+  const bool b16 = h->cfg.precision == CRNN_BF16;
   ConvGemm p{};
-  p.A = A; p.Wt = Wt; p.bias = bias; p.C = C; p.wvalid = nullptr;
+  p.A = (const float*)A; p.Wt = b16 ? (const float*)Wt16 : Wt; p.bias = bias; p.C = (float*)C; p.wvalid = nullptr;
   p.M = M; p.N = N; p.K = K; p.ldc = N;
   p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
-  launch_conv_gemm(p, h->cur->stream);
-  kmark(h, name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+  if (b16) launch_conv_gemm_bf16(p, out_bf16, h->cur->stream);
+  else launch_conv_gemm(p, h->cur->stream);
+  const double es = b16 ? 2.0 : 4.0;
+  kmark(h, name, 2.0 * M * N * K, es * ((double)M * K + (double)N * K) + ((b16 && out_bf16) ? 2.0 : 4.0) * M * N);
 }
 
-void conv(crnn_handle* h, int layer, const float* A, float* C, const int32_t* wvalid, int n, int Hin, int Win,
+void conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
           int Cin, int Hout, int Wout) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
+  const bool b16 = h->cfg.precision == CRNN_BF16;
   ConvGemm p{};
-  p.A = A; p.Wt = h->d_conv_w[layer]; p.bias = h->d_conv_b[layer]; p.C = C; p.wvalid = wvalid;
+  p.A = (const float*)A; p.Wt = b16 ? (const float*)h->db_conv_w[layer] : h->d_conv_w[layer];
+  p.bias = h->d_conv_b[layer]; p.C = (float*)C; p.wvalid = wvalid;
   p.M = n * Hout * Wout; p.N = NM[layer]; p.K = KS[layer] * KS[layer] * Cin; p.ldc = NM[layer];
   p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
   p.ks = KS[layer]; p.pad = KS[layer] == 3 ? 1 : 0;
   p.act = h->cfg.leaky_relu ? 2 : 1;
-  launch_conv_gemm(p, h->cur->stream);
+  if (b16) launch_conv_gemm_bf16(p, true, h->cur->stream);
+  else launch_conv_gemm(p, h->cur->stream);
+  const double es = b16 ? 2.0 : 4.0;
   kmark(h, names[layer], 2.0 * p.M * p.N * p.K,
-        4.0 * ((double)n * Hin * Win * Cin + (double)p.N * p.K + (double)p.M * p.N));
+        es * ((double)n * Hin * Win * Cin + (double)p.N * p.K + (double)p.M * p.N));
 }
 
 // Runs the network on the normalised input already in plan.x.  widths: host
@@ -339,34 +369,44 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   hipStream_t s = h->cur->stream;
   HIPCHK(h, hipEventRecord(h->cur->ev[1], s));
   const double dn = n;
-  launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
-  kmark(h, "conv0_pool0", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * (dn * 32 * g.W + dn * 16 * g.W1 * 64));
+  const bool b16 = h->cfg.precision == CRNN_BF16;
+  const double es = b16 ? 2.0 : 4.0;
+  if (b16) launch_conv0_pool_bf16(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
+  else launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
+  kmark(h, "conv0_pool0", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * dn * 32 * g.W + es * dn * 16 * g.W1 * 64);
   conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1);
-  launch_pool_2x2s2(p.c1, p.p1, n, 16, g.W1, 128, s);
-  kmark(h, "pool1", 0, 4.0 * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
+  if (b16) launch_pool_2x2s2_bf16(p.c1, p.p1, n, 16, g.W1, 128, s);
+  else launch_pool_2x2s2(p.c1, p.p1, n, 16, g.W1, 128, s);
+  kmark(h, "pool1", 0, es * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
   conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2);
   conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2);
-  launch_pool_2x2s21p01(p.c3, p.p2, n, 8, g.W2, 256, s);
-  kmark(h, "pool2", 0, 4.0 * (dn * 8 * g.W2 * 256 + dn * 4 * g.W3 * 256));
+  if (b16) launch_pool_2x2s21p01_bf16(p.c3, p.p2, n, 8, g.W2, 256, s);
+  else launch_pool_2x2s21p01(p.c3, p.p2, n, 8, g.W2, 256, s);
+  kmark(h, "pool2", 0, es * (dn * 8 * g.W2 * 256 + dn * 4 * g.W3 * 256));
   conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3);
   conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3);
-  launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
-  kmark(h, "pool3", 0, 4.0 * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
+  if (b16) launch_pool_2x2s21p01_bf16(p.c5, p.p3, n, 4, g.W3, 512, s);
+  else launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
+  kmark(h, "pool3", 0, es * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
   conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T);
   HIPCHK(h, hipEventRecord(h->cur->ev[2], s));
   const int M = n * g.T;
-  const double recflop = 2.0 * M * 2 * 1024 * 256, recbytes = 4.0 * ((double)M * 2048 + (double)M * 512 + 2 * 1024 * 256);
+  const double recflop = 2.0 * M * 2 * 1024 * 256;
+  const double recbytes = 4.0 * M * 2048 + es * ((double)M * 512 + 2 * 1024 * 256);
+  auto rec = [&](int l, float* out) {
+    if (b16) launch_lstm_rec_bf16(p.xp, h->db_whhp[l], out, tlen, n, g.T, s);
+    else launch_lstm_rec(p.xp, h->d_whhp[l], out, tlen, n, g.T, s);
+    kmark(h, l ? "lstm1_rec" : "lstm0_rec", recflop, recbytes);
+  };
   if (h->cfg.lstm) {
-    gemm(h, "lstm0_ih", p.seq, h->d_wih[0], h->d_bih[0], p.xp, M, 2048, 512);
-    launch_lstm_rec(p.xp, h->d_whhp[0], p.rec0, tlen, n, g.T, s);
-    kmark(h, "lstm0_rec", recflop, recbytes);
-    gemm(h, "emb0", p.rec0, h->d_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512);
-    gemm(h, "lstm1_ih", p.mid, h->d_wih[1], h->d_bih[1], p.xp, M, 2048, 256);
-    launch_lstm_rec(p.xp, h->d_whhp[1], p.rec1, tlen, n, g.T, s);
-    kmark(h, "lstm1_rec", recflop, recbytes);
-    gemm(h, "classifier", p.rec1, h->d_emb_w[1], h->d_emb_b[1], p.logits, M, h->cfg.nclass, 512);
+    gemm(h, "lstm0_ih", p.seq, h->d_wih[0], h->db_wih[0], h->d_bih[0], p.xp, M, 2048, 512, false);
+    rec(0, p.rec0);
+    gemm(h, "emb0", p.rec0, h->d_emb_w[0], h->db_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512, true);
+    gemm(h, "lstm1_ih", p.mid, h->d_wih[1], h->db_wih[1], h->d_bih[1], p.xp, M, 2048, 256, false);
+    rec(1, p.rec1);
+    gemm(h, "classifier", p.rec1, h->d_emb_w[1], h->db_emb_w[1], h->d_emb_b[1], p.logits, M, h->cfg.nclass, 512, false);
   } else {
-    gemm(h, "classifier", p.seq, h->d_lin_w, h->d_lin_b, p.logits, M, h->cfg.nclass, 512);
+    gemm(h, "classifier", p.seq, h->d_lin_w, h->db_lin_w, h->d_lin_b, p.logits, M, h->cfg.nclass, 512, false);
   }
   HIPCHK(h, hipEventRecord(h->cur->ev[3], s));
   launch_argmax(p.logits, p.raw, M, h->cfg.nclass, h->cfg.nclass, s);
@@ -485,6 +525,7 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   if (!cfg || !out) return CRNN_ERR_ARG;
   *out = nullptr;
   if (cfg->img_h != 32 || cfg->nc != 1 || cfg->nh != 256 || cfg->nclass < 2) return CRNN_ERR_ARG;
+  if (cfg->precision != CRNN_FP32 && cfg->precision != CRNN_BF16) return CRNN_ERR_ARG;
   crnn_handle* h = new (std::nothrow) crnn_handle();
   if (!h) return CRNN_ERR_NOMEM;
   h->cfg = *cfg;
@@ -579,6 +620,24 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
     if (!lb) return fail(h, CRNN_ERR_ARG, err);
     h->h_lin_w.assign(lw, lw + (size_t)nclass * 2 * nh);
     h->h_lin_b.assign(lb, lb + nclass);
+  }
+  if (h->cfg.precision == CRNN_BF16) {
+    auto cvt = [](const std::vector<float>& src, std::vector<uint16_t>& dst) {
+      dst.resize(src.size());
+      for (size_t i = 0; i < src.size(); i++) dst[i] = f32_to_bf16_host(src[i]);
+    };
+    for (int i = 1; i < 7; i++) cvt(h->h_conv_w[i], h->hb_conv_w[i]);
+    if (h->cfg.lstm) {
+      for (int l = 0; l < 2; l++) {
+        cvt(h->h_wih[l], h->hb_wih[l]);
+        cvt(h->h_emb_w[l], h->hb_emb_w[l]);
+        const std::string pr = "rnn." + std::to_string(l) + ".rnn.";
+        h->hb_whhp[l].resize((size_t)2 * 4 * nh * nh);
+        pack_whh_bf16(m[pr + "weight_hh_l0"]->data, m[pr + "weight_hh_l0_reverse"]->data, h->hb_whhp[l].data());
+      }
+    } else {
+      cvt(h->h_lin_w, h->hb_lin_w);
+    }
   }
   h->loaded = true;
   return 0;
@@ -731,6 +790,15 @@ int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const
   if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->cur->stream));
   if ((size_t)out_floats < h->cur->st_floats[stage]) return fail(h, CRNN_ERR_ARG, "out_host too small for this stage");
+  if (h->cfg.precision == CRNN_BF16 && stage != 10) {   // stored as bf16 on the device: widen for the caller
+    std::vector<uint16_t> tmp(h->cur->st_floats[stage]);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->cur->st[stage], tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); i++) {
+      const uint32_t u = (uint32_t)tmp[i] << 16;
+      memcpy(&out_host[i], &u, 4);
+    }
+    return 0;
+  }
   HIPCHK(h, hipMemcpy(out_host, h->cur->st[stage], h->cur->st_floats[stage] * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -802,7 +870,9 @@ void crnn_destroy(crnn_handle* h) {
       (void)hipFree(h->d_wih[l]); (void)hipFree(h->d_bih[l]); (void)hipFree(h->d_whhp[l]);
       (void)hipFree(h->d_emb_w[l]); (void)hipFree(h->d_emb_b[l]);
     }
-    (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b);
+    (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->db_lin_w);
+    for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
+    for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }
     for (int l = 0; l < h->nlanes; l++) {
       Lane& L = h->lanes[l];
       (void)hipFree(L.arena.p); (void)hipFree(L.pre.p); (void)hipFree(L.io.p);

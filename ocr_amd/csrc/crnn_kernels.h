@@ -74,4 +74,17 @@ void launch_resize_h(const uint8_t* src, const ResizeJob* jobs, const int32_t* c
 void launch_resize_v(const uint8_t* src, const ResizeJob* jobs, const int32_t* coef, const uint8_t* tmp,
                      float* out, int n, int Wp, hipStream_t s);
 
+// bf16 path (crnn_kernels_bf16.hip): bf16 activations and weights, fp32 accumulation ----------
+// ConvGemm is reused with A / Wt (and C when out_bf16) pointing at bf16 data; K % 64 == 0.
+void launch_conv_gemm_bf16(const ConvGemm& p, bool out_bf16, hipStream_t s);
+void launch_conv0_pool_bf16(const float* in, const float* w9x64, const float* bias, void* out,
+                            const int32_t* w1valid, int B, int W, int act, hipStream_t s);
+void launch_pool_2x2s2_bf16(const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
+void launch_pool_2x2s21p01_bf16(const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
+// xp fp32 [B*T][2048]; whh_packed from pack_whh_bf16; rec bf16 [B*T][512]
+void launch_lstm_rec_bf16(const float* xp, const void* whh_packed, void* rec, const int32_t* tlen, int B,
+                          int T, hipStream_t s);
+uint16_t f32_to_bf16_host(float f);
+void pack_whh_bf16(const float* whh_fwd, const float* whh_rev, uint16_t* packed /* 2*1024*256 */);
+
 }  // namespace crnn

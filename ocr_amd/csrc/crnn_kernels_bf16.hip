@@ -1,0 +1,430 @@
+// gfx950 kernels of the bf16 path: bf16 activations / weights, fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16), fp32 bias, gates and logits.
+// Same structure and the same NHWC / batch-major layouts as the fp32 kernels in
+// crnn_kernels.hip; this path reports character-level agreement with fp32, it is not
+// held to the 1e-3 logit bound.
+#include "crnn_kernels.h"
+
+namespace crnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// Implicit-GEMM convolution / GEMM, bf16 operands.  128x128 tile, BK = 64 bf16
+// (the same 128 bytes per row per K-tile as the fp32 kernel), rows padded to
+// 144 bytes in LDS, one LDS buffer + register prefetch, raw buffer loads.
+// MFMA 32x32x16: lane l holds A[row l&31][k = 8*(l>>5) + 0..7] as one 16-byte
+// LDS read; 4 k-steps per K-tile, 2x2 tiles per wave.
+// ---------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BKH = 64, LDB = 144;  // LDB: LDS row stride in bytes
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256, 3) void conv_gemm_bf16_kernel(const ConvGemm p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int bm = blockIdx.x / ntn, bn = blockIdx.x - bm * ntn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int lrow = tid >> 3;
+  const int lk = (tid & 7) * 8;  // bf16 elements
+  const int hw = p.Hout * p.Wout;
+  const __bf16* A = (const __bf16*)p.A;
+  const __bf16* Wt = (const __bf16*)p.Wt;
+
+  const long shift = ((long)p.pad * p.Win + p.pad) * p.Cin;
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(A - shift), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, 0x7FFFFFFF, 0x00020000);
+  unsigned aoff[4], amask[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int m = m0 + lrow + 32 * i;
+    m = m < p.M ? m : p.M - 1;
+    const int b = m / hw, r = m - b * hw;
+    const int y = r / p.Wout, x = r - y * p.Wout;
+    aoff[i] = (unsigned)(((((long)b * p.Hin + y) * p.Win + x) * p.Cin + lk) * 2);
+    unsigned mk = 0;
+    for (int ky = 0; ky < p.ks; ky++)
+      for (int kx = 0; kx < p.ks; kx++) {
+        const int yy = y - p.pad + ky, xx = x - p.pad + kx;
+        if ((unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win) mk |= 1u << (ky * p.ks + kx);
+      }
+    amask[i] = mk;
+    int n = n0 + lrow + 32 * i;
+    n = n < p.N ? n : p.N - 1;
+    boff[i] = (unsigned)(((long)n * p.K + lk) * 2);
+  }
+  const int nk = p.K / BKH;
+  i32x4 ra[4], rb[4];
+  int l_tap = 0, l_ky = 0, l_kx = 0, l_ci = 0, l_k0 = 0;
+  auto gload = [&]() {
+    const int toff = ((l_ky * p.Win + l_kx) * p.Cin + l_ci) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const unsigned vo = ((amask[i] >> l_tap) & 1u) ? aoff[i] : 0x80000000u;
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, vo, toff, 0);
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, boff[i], l_k0 * 2, 0);
+    }
+    l_k0 += BKH;
+    l_ci += BKH;
+    const bool wrap_c = l_ci == p.Cin;
+    l_ci = wrap_c ? 0 : l_ci;
+    l_tap += wrap_c ? 1 : 0;
+    l_kx += wrap_c ? 1 : 0;
+    const bool wrap_x = l_kx == p.ks;
+    l_kx = wrap_x ? 0 : l_kx;
+    l_ky += wrap_x ? 1 : 0;
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      *(i32x4*)(smem + (lrow + 32 * i) * LDB + lk * 2) = ra[i];
+      *(i32x4*)(smem + BM * LDB + (lrow + 32 * i) * LDB + lk * 2) = rb[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  auto compute = [&]() {
+    const unsigned char* a = smem + (wm * 64 + (lane & 31)) * LDB + 16 * (lane >> 5);
+    const unsigned char* b = smem + BM * LDB + (wn * 64 + (lane & 31)) * LDB + 16 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const bf16x8 a0 = *(const bf16x8*)(a + ks * 32);
+      const bf16x8 a1 = *(const bf16x8*)(a + 32 * LDB + ks * 32);
+      const bf16x8 b0 = *(const bf16x8*)(b + ks * 32);
+      const bf16x8 b1 = *(const bf16x8*)(b + 32 * LDB + ks * 32);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  };
+  gload();
+  sstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk - 1; kt++) {
+    gload();
+    compute();
+    __syncthreads();
+    sstore();
+    __syncthreads();
+  }
+  compute();
+
+#pragma unroll
+  for (int nt = 0; nt < 2; nt++) {
+    const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
+    const bool nok = n < p.N;
+    const float bias = nok ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[mt][nt][r] + bias;
+        if (p.act == 1) v = v > 0.f ? v : 0.f;
+        else if (p.act == 2) v = v > 0.f ? v : 0.2f * v;
+        if (row < p.M) {
+          if (p.wvalid) {
+            int b = row / hw, rr = row - b * hw;
+            int x = rr % p.Wout;
+            if (x >= p.wvalid[b]) v = 0.f;
+          }
+          if (nok) {
+            if (OUT_BF16) ((__bf16*)p.C)[(long)row * p.ldc + n] = (__bf16)v;
+            else p.C[(long)row * p.ldc + n] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+void launch_conv_gemm_bf16(const ConvGemm& p, bool out_bf16, hipStream_t s) {
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  if (out_bf16) hipLaunchKernelGGL(conv_gemm_bf16_kernel<true>, dim3(ntm * ntn), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(conv_gemm_bf16_kernel<false>, dim3(ntm * ntn), dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
+// conv0 + ReLU + pool0 (fp32 arithmetic on the fp32 input), bf16 NHWC output
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv0_pool_bf16_kernel(const float* __restrict__ in,
+                                                              const float* __restrict__ w9x64,
+                                                              const float* __restrict__ bias,
+                                                              __bf16* __restrict__ out,
+                                                              const int32_t* __restrict__ w1valid, int B,
+                                                              int W, int act) {
+  const int W1 = W >> 1;
+  const int cg = threadIdx.x & 15;
+  const long npix = (long)B * 16 * W1;
+  f32x4 wr[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++) wr[t] = *(const f32x4*)(w9x64 + t * 64 + cg * 4);
+  const f32x4 bs = *(const f32x4*)(bias + cg * 4);
+  for (long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long)gridDim.x * 16) {
+    const int b = (int)(pix / (16 * W1));
+    const int r = (int)(pix - (long)b * 16 * W1);
+    const int y1 = r / W1, x1 = r - y1 * W1;
+    const float* ip = in + (long)b * 32 * W;
+    float patch[4][4];
+#pragma unroll
+    for (int dy = 0; dy < 4; dy++) {
+      const int yy = 2 * y1 - 1 + dy;
+#pragma unroll
+      for (int dx = 0; dx < 4; dx++) {
+        const int xx = 2 * x1 - 1 + dx;
+        const bool ok = (unsigned)yy < 32u && (unsigned)xx < (unsigned)W;
+        patch[dy][dx] = ok ? ip[yy * W + xx] : 0.f;
+      }
+    }
+    f32x4 best;
+#pragma unroll
+    for (int py = 0; py < 2; py++)
+#pragma unroll
+      for (int px = 0; px < 2; px++) {
+        f32x4 a = bs;
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++) a += wr[ky * 3 + kx] * patch[py + ky][px + kx];
+        if (py == 0 && px == 0) best = a;
+        else {
+#pragma unroll
+          for (int c = 0; c < 4; c++) best[c] = a[c] > best[c] ? a[c] : best[c];
+        }
+      }
+    bf16x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      float v = best[c];
+      if (act == 1) v = v > 0.f ? v : 0.f;
+      else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+      if (w1valid && x1 >= w1valid[b]) v = 0.f;
+      o[c] = (__bf16)v;
+    }
+    *(bf16x4*)(out + pix * 64 + cg * 4) = o;
+  }
+}
+
+void launch_conv0_pool_bf16(const float* in, const float* w9x64, const float* bias, void* out,
+                            const int32_t* w1valid, int B, int W, int act, hipStream_t s) {
+  long npix = (long)B * 16 * (W >> 1);
+  long blocks = (npix + 15) / 16;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(conv0_pool_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, w9x64, bias,
+                     (__bf16*)out, w1valid, B, W, act);
+}
+
+// ---------------------------------------------------------------------------
+// NHWC max pools on bf16 (8 channels per 16-byte access; max is exact)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 max8(bf16x8 a, bf16x8 b) {
+  bf16x8 r;
+#pragma unroll
+  for (int c = 0; c < 8; c++) r[c] = (float)a[c] > (float)b[c] ? a[c] : b[c];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void pool_2x2s2_bf16_kernel(const __bf16* __restrict__ in,
+                                                              __bf16* __restrict__ out, int B, int H,
+                                                              int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, C8 = C >> 3;
+  const long total = (long)B * Ho * Wo * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long pix = i / C8;
+    const int x = (int)(pix % Wo);
+    pix /= Wo;
+    const int y = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    const __bf16* p = in + (((long)b * H + 2 * y) * W + 2 * x) * C + c8 * 8;
+    bf16x8 v = max8(max8(*(const bf16x8*)p, *(const bf16x8*)(p + C)),
+                    max8(*(const bf16x8*)(p + (long)W * C), *(const bf16x8*)(p + (long)W * C + C)));
+    *(bf16x8*)(out + i * 8) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_2x2s21p01_bf16_kernel(const __bf16* __restrict__ in,
+                                                                  __bf16* __restrict__ out, int B, int H,
+                                                                  int W, int C) {
+  const int Ho = H >> 1, Wo = W + 1, C8 = C >> 3;
+  const long total = (long)B * Ho * Wo * C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long pix = i / C8;
+    const int x = (int)(pix % Wo);
+    pix /= Wo;
+    const int y = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    const __bf16* r0 = in + (((long)b * H + 2 * y) * W) * C + c8 * 8;
+    const __bf16* r1 = r0 + (long)W * C;
+    bf16x8 v;
+    if (x < W) {
+      v = max8(*(const bf16x8*)(r0 + (long)x * C), *(const bf16x8*)(r1 + (long)x * C));
+      if (x > 0) v = max8(v, max8(*(const bf16x8*)(r0 + (long)(x - 1) * C), *(const bf16x8*)(r1 + (long)(x - 1) * C)));
+    } else {
+      v = max8(*(const bf16x8*)(r0 + (long)(x - 1) * C), *(const bf16x8*)(r1 + (long)(x - 1) * C));
+    }
+    *(bf16x8*)(out + i * 8) = v;
+  }
+}
+
+static unsigned ew_blocks16(long total) {
+  long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+void launch_pool_2x2s2_bf16(const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+  long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(pool_2x2s2_bf16_kernel, dim3(ew_blocks16(total)), dim3(256), 0, s, (const __bf16*)in,
+                     (__bf16*)out, B, H, W, C);
+}
+void launch_pool_2x2s21p01_bf16(const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+  long total = (long)B * (H / 2) * (W + 1) * (C / 8);
+  hipLaunchKernelGGL(pool_2x2s21p01_bf16_kernel, dim3(ew_blocks16(total)), dim3(256), 0, s,
+                     (const __bf16*)in, (__bf16*)out, B, H, W, C);
+}
+
+// ---------------------------------------------------------------------------
+// LSTM recurrence, bf16 operands.  One 256-thread workgroup per (direction, 16
+// lines) as in the fp32 kernel; gates^T = W_hh . h^T on v_mfma_f32_16x16x32_bf16
+// (lane l: A[row l&15][k = 8*(l>>4)+0..7], B[k = 8*(l>>4)+0..7][col l&15]).
+// W_hh (bf16, 512 KiB per direction) streams from L2 in packed fragment order;
+// h is kept in LDS as bf16 (the MFMA operand), c and the gates in fp32.
+// ---------------------------------------------------------------------------
+constexpr int LB = 16, HSB = 264;  // HSB: bf16 elements per h row in LDS (528 bytes)
+
+__device__ __forceinline__ float sigmoid_b(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * x));
+}
+__device__ __forceinline__ float tanh_b(float x) {
+  const float t = __builtin_amdgcn_exp2f(-2.885390082f * __builtin_fabsf(x));
+  const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+  return __builtin_copysignf(r, x);
+}
+
+__global__ __launch_bounds__(256) void lstm_rec_bf16_kernel(const float* __restrict__ xp,
+                                                            const __bf16* __restrict__ whhp,
+                                                            __bf16* __restrict__ rec,
+                                                            const int32_t* __restrict__ tlen, int B, int T) {
+  __shared__ __attribute__((aligned(16))) __bf16 hs[2 * LB * HSB];
+  const int dir = blockIdx.y, b0 = blockIdx.x * LB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
+  const int b = b0 + bl;
+  const int Ti = (b < B) ? (tlen ? tlen[b] : T) : 0;
+  int Tmax = 0;
+  for (int j = 0; j < LB; j++) {
+    int bb = b0 + j;
+    int tj = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
+    Tmax = tj > Tmax ? tj : Tmax;
+  }
+  for (int i = tid; i < 2 * LB * HSB; i += 256) hs[i] = (__bf16)0.f;
+  float c[4][4], h[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { c[u][r] = 0.f; h[u][r] = 0.f; }
+  // packed: [dir][wave][kstep 8][tile 16][lane 64] x 8 bf16
+  const bf16x8* wp = (const bf16x8*)whhp + ((size_t)(dir * 4 + wave) * 8 * 16) * 64 + lane;
+  __syncthreads();
+  int cur = 0;
+  for (int s = 0; s < Tmax; s++) {
+    const bool active = s < Ti;
+    const int t = active ? (dir ? (Ti - 1 - s) : s) : 0;
+    const size_t rowi = (size_t)(b < B ? b : 0) * T + t;
+    const float* xrow = xp + rowi * 2048 + dir * 1024 + wave * 64 + q * 4;
+    f32x4 xg[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        xg[g][u] = active ? *(const f32x4*)(xrow + g * 256 + u * 16) : z;
+      }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __bf16* hrow = hs + cur * LB * HSB + bl * HSB + 8 * q;
+#pragma unroll 2
+    for (int ks = 0; ks < 8; ks++) {
+      const bf16x8 hv = *(const bf16x8*)(hrow + ks * 32);
+#pragma unroll
+      for (int tile = 0; tile < 16; tile++) {
+        const bf16x8 av = wp[(size_t)(ks * 16 + tile) * 64];
+        acc[tile >> 2][tile & 3] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hv, acc[tile >> 2][tile & 3], 0, 0, 0);
+      }
+    }
+    __bf16* hn = hs + (cur ^ 1) * LB * HSB + bl * HSB + wave * 64 + q * 4;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      bf16x4 hv4;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (active) {
+          const float ig = sigmoid_b(acc[0][u][r] + xg[0][u][r]);
+          const float fg = sigmoid_b(acc[1][u][r] + xg[1][u][r]);
+          const float gg = tanh_b(acc[2][u][r] + xg[2][u][r]);
+          const float og = sigmoid_b(acc[3][u][r] + xg[3][u][r]);
+          c[u][r] = fg * c[u][r] + ig * gg;
+          h[u][r] = og * tanh_b(c[u][r]);
+        }
+        hv4[r] = (__bf16)h[u][r];
+      }
+      *(bf16x4*)(hn + u * 16) = hv4;
+      if (active) *(bf16x4*)(rec + rowi * 512 + dir * 256 + wave * 64 + u * 16 + q * 4) = hv4;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+void launch_lstm_rec_bf16(const float* xp, const void* whh_packed, void* rec, const int32_t* tlen, int B,
+                          int T, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_rec_bf16_kernel, dim3((B + LB - 1) / LB, 2), dim3(256), 0, s, xp,
+                     (const __bf16*)whh_packed, (__bf16*)rec, tlen, B, T);
+}
+
+// host: fp32 -> bf16 round-to-nearest-even (finite weights)
+uint16_t f32_to_bf16_host(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+void pack_whh_bf16(const float* whh_fwd, const float* whh_rev, uint16_t* packed) {
+  for (int dir = 0; dir < 2; dir++) {
+    const float* w = dir ? whh_rev : whh_fwd;
+    for (int wave = 0; wave < 4; wave++)
+      for (int ks = 0; ks < 8; ks++)
+        for (int tile = 0; tile < 16; tile++)
+          for (int lane = 0; lane < 64; lane++) {
+            const int g = tile >> 2, u = tile & 3, q = lane >> 4, bl = lane & 15;
+            const int row = g * 256 + wave * 64 + u * 16 + bl;
+            const int k = ks * 32 + 8 * q;
+            uint16_t* dst = packed + ((((size_t)(dir * 4 + wave) * 8 + ks) * 16 + tile) * 64 + lane) * 8;
+            for (int j = 0; j < 8; j++) dst[j] = f32_to_bf16_host(w[(size_t)row * 256 + k + j]);
+          }
+  }
+}
+
+}  // namespace crnn

@@ -23,9 +23,9 @@ def test_host_only_calls_and_errors():
     lib = _capi.lib()
     assert lib.crnn_out_len(280) == 71 and lib.crnn_out_len(1024) == 257 and lib.crnn_out_len(8) == 3
     h = C.c_void_p()
-    bad = _capi.Config(48, 1, 65, 256, 0, 1, 0, 0)
+    bad = _capi.Config(48, 1, 65, 256, 0, 1, 0, 0, 0, 0)
     assert lib.crnn_create(C.byref(bad), C.byref(h)) == _capi.CRNN_ERR_ARG
-    cfg = _capi.Config(32, 1, 65, 256, 0, 1, 0, 0)
+    cfg = _capi.Config(32, 1, 65, 256, 0, 1, 0, 0, 0, 0)
     assert lib.crnn_create(C.byref(cfg), C.byref(h)) == 0
     assert lib.crnn_resized_width(h, 537, 91) == 188   # invoice_code.png: int(537 / (91 / 32.0))
     assert lib.crnn_resized_width(h, 10, 0) == _capi.CRNN_ERR_ZERO_H
