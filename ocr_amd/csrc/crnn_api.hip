@@ -579,10 +579,21 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
         for (int ky = 0; ky < k; ky++)
           for (int kx = 0; kx < k; kx++) {
             const float v = (float)((double)w[(((size_t)o * cin + c) * k + ky) * k + kx] * sc);
-            if (i == 0)
+            if (i == 0) {
               h->h_conv_w[0][(size_t)(ky * 3 + kx) * 64 + o] = v;  // [tap][co] for the direct kernel
-            else
-              h->h_conv_w[i][(((size_t)o * k + ky) * k + kx) * cin + c] = v;  // [co][ky][kx][ci]
+            } else {
+              // K order (channel chunk, ky, kx, channel in chunk): the taps of one chunk are
+              // consecutive K-tiles, so the 3x3 neighbourhood re-reads of a chunk hit L1/L2
+              // instead of going back to the fabric (chunk = one K-tile: 32 fp32 / 64 bf16).
+              const int ch = 32;
+              h->h_conv_w[i][(size_t)o * k * k * cin + ((size_t)(c / ch) * k * k + ky * k + kx) * ch + c % ch] = v;
+              if (h->cfg.precision == CRNN_BF16) {
+                const int cb = 64;
+                if (h->hb_conv_w[i].empty()) h->hb_conv_w[i].assign((size_t)co * k * k * cin, 0);
+                h->hb_conv_w[i][(size_t)o * k * k * cin + ((size_t)(c / cb) * k * k + ky * k + kx) * cb + c % cb] =
+                    f32_to_bf16_host(v);
+              }
+            }
           }
     }
   }
@@ -626,7 +637,6 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
       dst.resize(src.size());
       for (size_t i = 0; i < src.size(); i++) dst[i] = f32_to_bf16_host(src[i]);
     };
-    for (int i = 1; i < 7; i++) cvt(h->h_conv_w[i], h->hb_conv_w[i]);
     if (h->cfg.lstm) {
       for (int l = 0; l < 2; l++) {
         cvt(h->h_wih[l], h->hb_wih[l]);

@@ -86,15 +86,17 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ConvGemm p) {
       ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, vo, toff, 0));
       rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, boff[i], l_k0 * 4, 0));
     }
+    // next K-tile: taps cycle fastest, then the channel chunk (weights are packed in this order)
     l_k0 += BK;
-    l_ci += BK;
-    const bool wrap_c = l_ci == p.Cin;
-    l_ci = wrap_c ? 0 : l_ci;
-    l_tap += wrap_c ? 1 : 0;
-    l_kx += wrap_c ? 1 : 0;
+    l_tap++;
+    l_kx++;
     const bool wrap_x = l_kx == p.ks;
     l_kx = wrap_x ? 0 : l_kx;
     l_ky += wrap_x ? 1 : 0;
+    const bool wrap_t = l_ky == p.ks;
+    l_ky = wrap_t ? 0 : l_ky;
+    l_tap = wrap_t ? 0 : l_tap;
+    l_ci += wrap_t ? BK : 0;
   };
   auto sstore = [&]() {
     float* sa = smem;
