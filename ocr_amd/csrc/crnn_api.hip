@@ -271,6 +271,8 @@ struct Plan {
   float *x, *p0, *c1, *p1, *c2, *c3, *p2, *c4, *c5, *p3, *seq, *xp, *rec0, *mid, *rec1, *logits;
   int32_t *wl;   // [8][n] per-layer width arrays
   int32_t *raw;  // [n*T]
+  float* pmax;   // [n*T][n-tiles of the classifier]
+  int32_t* pidx;
   size_t bytes;
 };
 
@@ -301,6 +303,9 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
   p.logits = take(n * g.T * (size_t)h->cfg.nclass);
   p.wl = (int32_t*)take(8 * n);
   p.raw = (int32_t*)take(n * g.T);
+  const size_t ntn = ((size_t)h->cfg.nclass + 127) / 128;
+  p.pmax = take(n * g.T * ntn);
+  p.pidx = (int32_t*)take(n * g.T * ntn);
   p.bytes = off;
   return p;
 }
@@ -316,16 +321,19 @@ void kmark(crnn_handle* h, const char* name, double flop, double bytes) {
 
 // out_bf16 only matters on the bf16 path (which GEMM outputs feed another GEMM)
 void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, const uint16_t* Wt16,
-          const float* bias, void* C, int M, int N, int K, bool out_bf16) {
+          const float* bias, void* C, int M, int N, int K, bool out_bf16, float* pmax = nullptr,
+          int32_t* pidx = nullptr) {
   const bool b16 = h->cfg.precision == CRNN_BF16;
   ConvGemm p{};
   p.A = (const float*)A; p.Wt = b16 ? (const float*)Wt16 : Wt; p.bias = bias; p.C = (float*)C; p.wvalid = nullptr;
   p.M = M; p.N = N; p.K = K; p.ldc = N;
   p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
+  p.pmax = pmax; p.pidx = pidx;
   if (b16) launch_conv_gemm_bf16(p, out_bf16, h->cur->stream);
   else launch_conv_gemm(p, h->cur->stream);
   const double es = b16 ? 2.0 : 4.0;
-  kmark(h, name, 2.0 * M * N * K, es * ((double)M * K + (double)N * K) + ((b16 && out_bf16) ? 2.0 : 4.0) * M * N);
+  kmark(h, name, 2.0 * M * N * K,
+        es * ((double)M * K + (double)N * K) + (C ? ((b16 && out_bf16) ? 2.0 : 4.0) * M * N : 8.0 * M * ((N + 127) / 128)));
 }
 
 void conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
@@ -349,7 +357,7 @@ void conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
 // Runs the network on the normalised input already in plan.x.  widths: host
 // per-line valid widths or nullptr.  Outputs (device): plan.raw plus d_lab/d_len.
 int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widths, int32_t* d_lab,
-                int32_t* d_len) {
+                int32_t* d_len, bool want_logits = false) {
   const int n = g.n;
   const int act = h->cfg.leaky_relu ? 2 : 1;
   const int32_t *m_p0 = nullptr, *m_c1 = nullptr, *m_w2 = nullptr, *m_w3 = nullptr, *tlen = nullptr;
@@ -404,13 +412,17 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     gemm(h, "emb0", p.rec0, h->d_emb_w[0], h->db_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512, true);
     gemm(h, "lstm1_ih", p.mid, h->d_wih[1], h->db_wih[1], h->d_bih[1], p.xp, M, 2048, 256, false);
     rec(1, p.rec1);
-    gemm(h, "classifier", p.rec1, h->d_emb_w[1], h->db_emb_w[1], h->d_emb_b[1], p.logits, M, h->cfg.nclass, 512, false);
+    gemm(h, "classifier", p.rec1, h->d_emb_w[1], h->db_emb_w[1], h->d_emb_b[1], want_logits ? p.logits : nullptr, M,
+         h->cfg.nclass, 512, false, p.pmax, p.pidx);
   } else {
-    gemm(h, "classifier", p.seq, h->d_lin_w, h->db_lin_w, h->d_lin_b, p.logits, M, h->cfg.nclass, 512, false);
+    gemm(h, "classifier", p.seq, h->d_lin_w, h->db_lin_w, h->d_lin_b, want_logits ? p.logits : nullptr, M,
+         h->cfg.nclass, 512, false, p.pmax, p.pidx);
   }
   HIPCHK(h, hipEventRecord(h->cur->ev[3], s));
-  launch_argmax(p.logits, p.raw, M, h->cfg.nclass, h->cfg.nclass, s);
-  kmark(h, "argmax", 0, 4.0 * ((double)M * h->cfg.nclass + M));
+  // the classifier's epilogue left per-tile (max, index) partials: finish the arg-max over tiles
+  const int ntn = (h->cfg.nclass + 127) / 128;
+  launch_argmax_partials(p.pmax, p.pidx, p.raw, M, ntn, s);
+  kmark(h, "argmax", 0, 8.0 * M * ntn + 4.0 * M);
   launch_ctc(p.raw, tlen, d_lab, d_len, n, g.T, s);
   kmark(h, "ctc", 0, 4.0 * (2.0 * M + n));
   HIPCHK(h, hipEventRecord(h->cur->ev[4], s));
@@ -722,7 +734,7 @@ int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t
   if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, Wp, p.x))) return rc;
   std::vector<int32_t> wv(dw.begin(), dw.end());
   const bool uniform = pad_mode == CRNN_PAD_REFERENCE;
-  if ((rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len))) return rc;
+  if ((rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len, out_logits != nullptr))) return rc;
   std::vector<int32_t> lab(nT), raw(nT), len(g.n);
   HIPCHK(h, hipMemcpyAsync(lab.data(), d_lab, nT * 4, hipMemcpyDeviceToHost, h->cur->stream));
   HIPCHK(h, hipMemcpyAsync(raw.data(), p.raw, nT * 4, hipMemcpyDeviceToHost, h->cur->stream));
@@ -797,7 +809,7 @@ int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const
   int32_t* d_len = d_lab + ((nT + 63) / 64) * 64;
   HIPCHK(h, hipMemcpyAsync(p.x, x, sizeof(float) * (size_t)n * 32 * w, hipMemcpyHostToDevice, h->cur->stream));
   HIPCHK(h, hipEventRecord(h->cur->ev[0], h->cur->stream));
-  if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
+  if ((rc = run_network(h, g, p, widths, d_lab, d_len, true))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->cur->stream));
   if ((size_t)out_floats < h->cur->st_floats[stage]) return fail(h, CRNN_ERR_ARG, "out_host too small for this stage");
   if (h->cfg.precision == CRNN_BF16 && stage != 10) {   // stored as bf16 on the device: widen for the caller

@@ -20,9 +20,61 @@ struct ConvGemm {
   int M, N, K, ldc;
   int Hin, Win, Cin, Hout, Wout, ks, pad;
   int act;            // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
+  // fused arg-max epilogue (classifier): when pmax != nullptr every block writes, for each of its
+  // rows, the best value / lowest best column over ITS 128 columns to pmax/pidx[row][n-tile];
+  // C may then be nullptr (no logits written).  launch_argmax_partials finishes the reduction.
+  float* pmax;
+  int32_t* pidx;
 };
 
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
+
+#ifdef __HIPCC__
+// Arg-max epilogue shared by the fp32 and bf16 GEMM kernels.  acc is the wave's 2x2 set of 32x32
+// MFMA accumulators (C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  Per row: max
+// over the lane's two columns, butterfly max over the 32 lanes of the half-wave, then two ballots
+// find the lowest column holding the max (torch's tie rule).  The two N-waves of the block meet
+// in LDS (sv/si: 2 x 128 entries each).  Must be called by all 256 threads after a barrier that
+// ends the last LDS reads of the main loop.
+typedef float crnn_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void argmax_epilogue(const crnn_f32x16 (&acc)[2][2], const ConvGemm& p, float* sv,
+                                                int* si, int m0, int n0, int bn, int ntn, int wm, int wn,
+                                                int lane, int tid) {
+  const int half = lane >> 5;
+  const int c0 = n0 + wn * 64 + (lane & 31), c1 = c0 + 32;
+  const bool ok0 = c0 < p.N, ok1 = c1 < p.N;
+  const float b0 = ok0 ? p.bias[c0] : 0.f, b1 = ok1 ? p.bias[c1] : 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float v0 = ok0 ? acc[mt][0][r] + b0 : -INFINITY;
+      const float v1 = ok1 ? acc[mt][1][r] + b1 : -INFINITY;
+      float m = v0 > v1 ? v0 : v1;
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+      }
+      const unsigned long long q0 = __ballot(v0 == m), q1 = __ballot(v1 == m);
+      const unsigned h0 = half ? (unsigned)(q0 >> 32) : (unsigned)q0;
+      const unsigned h1 = half ? (unsigned)(q1 >> 32) : (unsigned)q1;
+      const int col = h0 ? __builtin_ctz(h0) : (h1 ? 32 + __builtin_ctz(h1) : 0);
+      if ((lane & 31) == 0) {
+        const int rl = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        sv[wn * 128 + rl] = m;
+        si[wn * 128 + rl] = n0 + wn * 64 + col;
+      }
+    }
+  __syncthreads();
+  if (tid < 128 && m0 + tid < p.M) {
+    const float a = sv[tid], b = sv[128 + tid];
+    const bool takeb = b > a;   // tie -> the lower columns (wave wn = 0)
+    p.pmax[(long)(m0 + tid) * ntn + bn] = takeb ? b : a;
+    p.pidx[(long)(m0 + tid) * ntn + bn] = takeb ? si[128 + tid] : si[tid];
+  }
+}
+#endif
 
 // conv0 (1->64, 3x3, pad 1) + ReLU + MaxPool 2x2/2, direct (K = 9, HBM-bound).
 // in f32 [B,32,W]; out NHWC [B,16,W/2,64]; w1valid: per-sample valid pooled width or nullptr.
@@ -41,6 +93,10 @@ void launch_lstm_rec(const float* xp, const float* whh_packed, float* rec, const
                      int B, int T, hipStream_t s);
 // host-side repack of W_hh [2][1024][256] into the per-lane fragment order the kernel streams.
 void pack_whh(const float* whh_fwd, const float* whh_rev, float* packed /* 2*1024*256 */);
+
+// second stage of the fused classifier arg-max: pmax/pidx [M][ntiles] -> idx [M] (ties -> lowest index)
+void launch_argmax_partials(const float* pmax, const int32_t* pidx, int32_t* idx, int M, int ntiles,
+                            hipStream_t s);
 
 // row-wise argmax over nclass (ties -> lowest index); logits [M][ld] -> idx [M]
 void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld, hipStream_t s);

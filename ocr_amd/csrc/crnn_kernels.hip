@@ -147,6 +147,12 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ConvGemm p) {
   }
   compute();
 
+  if (p.pmax) {   // fused classifier arg-max (wave-uniform branch)
+    __syncthreads();
+    argmax_epilogue(acc, p, smem, (int*)(smem + 256), m0, n0, bn, ntn, wm, wn, lane, tid);
+    if (!p.C) return;
+  }
+
   // epilogue: bias + activation + per-sample width mask.  C/D map of the 32x32
   // MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 #pragma unroll
@@ -496,6 +502,27 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
   if (lane == 0) idx[row] = bi;
+}
+
+__global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __restrict__ pmax,
+                                                              const int32_t* __restrict__ pidx,
+                                                              int32_t* __restrict__ idx, int M, int nt) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= M) return;
+  const float* pv = pmax + (long)row * nt;
+  const int32_t* pi = pidx + (long)row * nt;
+  float bv = pv[0];
+  int bi = pi[0];
+  for (int t = 1; t < nt; t++) {       // tiles are in column order: strict > keeps the lowest index
+    const float v = pv[t];
+    if (v > bv) { bv = v; bi = pi[t]; }
+  }
+  idx[row] = bi;
+}
+
+void launch_argmax_partials(const float* pmax, const int32_t* pidx, int32_t* idx, int M, int ntiles,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(argmax_partials_kernel, dim3((M + 255) / 256), dim3(256), 0, s, pmax, pidx, idx, M, ntiles);
 }
 
 void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld, hipStream_t s) {

@@ -125,6 +125,12 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16_kernel(const ConvGemm p
   }
   compute();
 
+  if (!OUT_BF16 && p.pmax) {   // fused classifier arg-max (wave-uniform branch)
+    __syncthreads();
+    argmax_epilogue(acc, p, (float*)smem, (int*)smem + 256, m0, n0, bn, ntn, wm, wn, lane, tid);
+    if (!p.C) return;
+  }
+
 #pragma unroll
   for (int nt = 0; nt < 2; nt++) {
     const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
