@@ -184,6 +184,18 @@ def main():
     kernels = {n: {"ms": round(acc[n][0], 4),
                    "tflops": round(acc[n][1] / (acc[n][0] * 1e-3) / 1e12, 2) if acc[n][1] else None,
                    "gbs_algorithmic": round(acc[n][2] / (acc[n][0] * 1e-3) / 1e9, 1)} for n in order}
+    # HBM traffic of the same launches from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, gfx950 x2 read correction; tools/pmc_traffic.py).  PMC counters
+    # cannot be collected from inside this process, so the figure comes from profiles/.
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "r1_pmc_traffic_%s.json" % args.precision)
+    if os.path.exists(tp):
+        with open(tp) as f:
+            tj = json.load(f)
+        if all(n in tj for n in gemm_names):
+            traffic = sum(tj[n]["hbm_bytes"] for n in gemm_names) / len(gemm_names)
+            traffic_src = "profiles/" + os.path.basename(tp)
+
     out = {
         "metric": "text-lines/sec at 32x280 crops (CRNN ocr-lstm head, 5530 classes)",
         "value": round(value, 1), "unit": "text-lines/s", "n_gpus": world, "steps": args.steps,
@@ -200,7 +212,9 @@ def main():
             "bound": "mfma", "kernel": ("conv_gemm_kernel" if args.precision == "fp32" else "conv_gemm_bf16_kernel") + " (implicit-GEMM conv1-6 + LSTM input projections + "
                                        "embedding + classifier, %d launches per step)" % len(gemm_names),
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (avg)",
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch_avg": sum(acc[n][2] for n in gemm_names) / max(1, len(gemm_names)),
             "flops_per_launch_avg": g_fl / max(1, len(gemm_names)),
             "ms_per_launch_avg": round(g_ms / max(1, len(gemm_names)), 4)},
         "pipeline_tflops": round(FLOP_PER_LINE * value / 1e12, 2),

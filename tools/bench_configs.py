@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Secondary measurements (BASELINE.json configs 3 and 5; config 2/4 are bench.py):
+  config 3: English head (65 classes), widths drawn from {64,96,...,1024}, width-bucketed, per-line
+            exact (masked) batches, device-resident lines; lines/s and padded-waste fraction.
+  config 5: page-level stand-in.  Detectors / their weights / images/vat are absent from the reference
+            snapshot, so a synthetic stream of BGR crops with the size distribution of the 17
+            images/invoice crops (tests/golden) is replayed through CRNN.predict_lines (host crops ->
+            gray -> Pillow-exact resize -> network -> strings); crops/s, PCIe-inclusive.
+Prints one JSON object; run on an MI355X:  python tools/bench_configs.py [--precision bf16]
+"""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--lines", type=int, default=16384)
+    args = ap.parse_args()
+    import torch
+    from ocr_amd.crnn import keys
+    from ocr_amd.crnn.batching import padded_waste, width_buckets
+    from ocr_amd.crnn.network_hip import CRNN
+    from ocr_amd.crnn.synth import synth_state_dict
+    dev = torch.device("cuda", 0)
+    out = {"precision": args.precision}
+
+    # ---------------- config 3
+    en = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish, device=0, lanes=3, precision=args.precision)
+    en.load_state_dict(synth_state_dict(65, seed=0))
+    rs = np.random.RandomState(3)
+    widths = [int(w) for w in rs.choice(np.arange(64, 1025, 32), size=args.lines)]
+    buckets = width_buckets(widths, max_batch=256, width_spread=1.25)
+    waste = padded_waste(widths, buckets)
+    # device-resident padded batches (uint8) + per-line widths
+    batches = []
+    for b in buckets:
+        wp = max(widths[i] for i in b)
+        g = torch.randint(0, 256, (len(b), 32, wp), dtype=torch.uint8, device=dev)
+        T = wp // 4 + 1
+        batches.append((g, [widths[i] for i in b], torch.zeros((len(b), T), dtype=torch.int32, device=dev),
+                        torch.zeros((len(b),), dtype=torch.int32, device=dev)))
+
+    def run3():
+        for g, wv, lab, ln in batches:
+            en.forward_device(g.data_ptr(), g.shape[0], g.shape[2], lab.data_ptr(), ln.data_ptr(), widths=wv)
+        en.synchronize()
+    run3()
+    t0 = time.perf_counter(); run3(); el = time.perf_counter() - t0
+    out["config3"] = {"lines": args.lines, "buckets": len(buckets), "padded_waste_frac": round(waste, 4),
+                      "lines_per_s": round(args.lines / el, 1), "seconds": round(el, 3),
+                      "mean_width": float(np.mean(widths)),
+                      "note": "65-class head, widths uniform over {64..1024 step 32}, per-line masked batches (== predict)"}
+
+    # ---------------- config 5 (crop replay)
+    zh = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1, precision=args.precision)
+    zh.load_state_dict(synth_state_dict(5530, seed=0))
+    G = np.load(os.path.join(ROOT, "tests", "golden", "crnn_golden.npz"))
+    shapes = [G[k].shape for k in G.files if k.startswith("inv/") and k.endswith("/bgr")]
+    ncrops = 2048
+    crops = []
+    for i in range(ncrops):
+        h, w, _ = shapes[rs.randint(len(shapes))]
+        crops.append(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8))
+    zh.predict_lines(crops[:64])
+    t0 = time.perf_counter(); texts = zh.predict_lines(crops); el = time.perf_counter() - t0
+    out["config5_crop_replay"] = {"crops": ncrops, "crops_per_s": round(ncrops / el, 1), "seconds": round(el, 3),
+                                  "note": "synthetic BGR crops with the 17 invoice crop sizes, host -> strings via "
+                                          "predict_lines (H2D + gray + resize included); detectors absent, no pages/s"}
+    assert len(texts) == ncrops
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -174,7 +174,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // Variant B: raw buffer loads.  voffset per lane is constant over the K loop (pixel / weight row
 // base, or 0x80000000-range OOB for padding taps via a per-tap select); the K position goes in
 // the scalar offset, so the loader needs ~1 VALU per load.
-template <int NBUF, int MINW>
+template <int NBUF, int MINW, int EPI = 0>
 __global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
   constexpr int BK_ = 32, BM = 128, BN = 128, LDT = BK_ + 4, KG = 4, NP = 4;
   __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LDT];
@@ -274,6 +274,43 @@ __global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
       gload(); compute(0); __syncthreads(); sstore(0); __syncthreads();
     }
     compute(0);
+  }
+  if (EPI == 1) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) asm volatile("" :: "v"(acc[a][b]));
+    return;
+  }
+  if (EPI == 2) {
+    // transpose through LDS: each wave stages its 64x64 tile (two 32-row halves at a time) and
+    // writes full 256-byte row segments with float4 stores
+    __syncthreads();
+    float* st = smem + wave * (32 * 68);            // 32 rows x 64 cols (+4 pad) per wave = 8704 B
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
+        const float bias = n < p.N ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float v = acc[mt][nt][r] + bias;
+          if (p.act == 1) v = v > 0.f ? v : 0.f;
+          st[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 68 + nt * 32 + (lane & 31)] = v;
+        }
+      }
+      // wave-local: 32 rows x 64 cols -> 16 lanes per row, 4 rows per pass, 8 passes
+#pragma unroll
+      for (int ps = 0; ps < 8; ps++) {
+        const int rl = ps * 4 + (lane >> 4);
+        const int row = m0 + wm * 64 + mt * 32 + rl;
+        const int col = n0 + wn * 64 + (lane & 15) * 4;
+        const f32x4 v = *(const f32x4*)(st + rl * 68 + (lane & 15) * 4);
+        if (row < p.M && col < p.N) *(f32x4*)(p.C + (long)row * p.ldc + col) = v;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int nt = 0; nt < 2; nt++) {
@@ -381,7 +418,9 @@ int main(int argc, char** argv) {
     RUN("bk32 nbuf2 (current)", 32, 2, 0, 2);
     RUN("bk32 nbuf1 minw3", 32, 1, 0, 3);
     RUNB("buffer loads nbuf1 minw3", 1, 3);
-    for (int ns = 2; ns <= 3; ns++) {
+    RUNB("  + no stores", 1, 3, 1);
+    RUNB("  + LDS-transposed f4 stores", 1, 3, 2);
+    for (int ns = 2; ns <= 1; ns++) {
       hipStream_t st[3];
       for (int i = 0; i < ns; i++) CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
       int k = 0;
