@@ -56,6 +56,21 @@ def cpu_baseline(lines_u8, sd, alphabet, want_seconds=12.0):
                       % (done, BATCH, cores, el)}, texts
 
 
+def char_agreement(got, want):
+    """1 - (sum of edit distances) / (sum of reference lengths)."""
+    err = tot = 0
+    for a, b in zip(got, want):
+        prev = list(range(len(b) + 1))
+        for i, ca in enumerate(a, 1):
+            cur = [i]
+            for j, cb in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+            prev = cur
+        err += prev[-1]
+        tot += len(b)
+    return 1.0 - err / max(1, tot)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +241,7 @@ def main():
         out["cpu_baseline"] = cb
         same = sum(a == b for a, b in zip(first_texts, cpu_texts))
         out["cpu_baseline"]["strings_identical_to_gpu"] = "%d/%d" % (same, len(cpu_texts))
+        out["cpu_baseline"]["char_agreement_gpu_vs_cpu_fp32"] = round(char_agreement(first_texts, cpu_texts), 4)
     print(json.dumps(out, ensure_ascii=False))
     if world > 1:
         dist.destroy_process_group()
