@@ -34,6 +34,31 @@ class Tensor(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so and load it
+    by its unversioned name, so it does not unify with the /opt/rocm copy this library links to; two
+    HIP/HSA runtimes in one process cannot both open the GPU.  If torch is installed (it is the
+    tensor plumbing of bench.py and of callers that hand over device pointers), load ITS runtime
+    first: this library's libamdhip64.so.7 dependency then resolves to the same object (same
+    SONAME), whichever of the two is imported first.  CRNN_HIP_RUNTIME=<path> overrides."""
+    path = os.environ.get("CRNN_HIP_RUNTIME")
+    if not path:
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")
+            if spec and spec.submodule_search_locations:
+                cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+                if os.path.exists(cand):
+                    path = cand
+        except Exception:  # noqa: BLE001
+            path = None
+    if path:
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -42,6 +67,7 @@ def lib():
         raise ImportError(
             "ocr_amd/libcrnn_hip.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C ocr_amd/csrc` (hipcc, gfx950).  There is no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_int32)
     L.crnn_create.restype = C.c_int

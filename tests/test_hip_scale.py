@@ -1,0 +1,184 @@
+"""Full-size behaviour of the HIP path through the C ABI (BASELINE.json configs 2-4 sizes), checked
+through size-independent properties, plus the serving conventions (threads, fork).  Needs an MI355X."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from ocr_amd.crnn import keys
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zh3(synth_zh):
+    from ocr_amd.crnn.network_hip import CRNN
+    m = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, lanes=3)
+    m.load_state_dict(synth_zh)
+    return m
+
+
+def _device_batch(model, lines, widths=None):
+    """forward_device on a uint8 [n,32,w] numpy batch -> (raw [n,T], lab [n,T], len [n]) on the host."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, _, w = lines.shape
+    T = w // 4 + 1
+    d = torch.from_numpy(lines).to(dev)
+    raw = torch.zeros((n, T), dtype=torch.int32, device=dev)
+    lab = torch.zeros((n, T), dtype=torch.int32, device=dev)
+    ln = torch.zeros((n,), dtype=torch.int32, device=dev)
+    model.forward_device(d.data_ptr(), n, w, lab.data_ptr(), ln.data_ptr(), d_raw_ptr=raw.data_ptr(), widths=widths)
+    model.synchronize()
+    return raw.cpu().numpy(), lab.cpu().numpy(), ln.cpu().numpy()
+
+
+def test_batch256_matches_golden_lines_anywhere_in_the_batch(golden, zh3):
+    """Config 2 size: 256 lines of 32x280.  The 12 golden lines are scattered through the batch; every
+    copy must decode to the reference's arg-max sequence wherever it sits (lines are independent), on
+    every lane, and repeated calls are bit-identical."""
+    G, M = golden
+    gold = np.concatenate([G["syn280/noise/gray"], G["syn280/text/gray"]])
+    want = np.concatenate([G["syn280/noise/zh_idx"], G["syn280/text/zh_idx"]])
+    rs = np.random.RandomState(5)
+    lines = rs.randint(0, 256, size=(256, 32, 280)).astype(np.uint8)
+    pos = rs.permutation(256)[:48]
+    for j, p in enumerate(pos):
+        lines[p] = gold[j % 12]
+    first = None
+    for _ in range(4):                     # rotates over the three lanes and back to lane 0
+        raw, lab, ln = _device_batch(zh3, lines)
+        for j, p in enumerate(pos):
+            assert np.array_equal(raw[p], want[j % 12])
+        if first is None:
+            first = (raw.copy(), lab.copy(), ln.copy())
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(first, (raw, lab, ln)))
+    # CTC collapse property on the device output: labels = collapse(raw) for every line
+    from ocr_amd.crnn.util import strLabelConverter
+    texts = zh3.texts_from_labels(lab, ln)
+    for i in (0, 17, 100, 255):
+        assert texts[i] == strLabelConverter(raw[i], keys.alphabetChinese)
+
+
+def test_masked_batch_equals_exact_width_batches(zh3):
+    """Config 3 shape: lines of different widths in ONE padded device batch (per-line masks) decode
+    exactly like the same lines run in batches of their own width."""
+    rs = np.random.RandomState(11)
+    widths = [1024, 1000, 640, 611, 333, 280, 96, 64, 9, 8] * 3
+    wp = max(widths)
+    lines = np.zeros((len(widths), 32, wp), np.uint8)
+    for i, w in enumerate(widths):
+        lines[i, :, :w] = rs.randint(0, 256, size=(32, w))
+        lines[i, :, w:] = rs.randint(0, 256, size=(32, wp - w))     # garbage right of the line must not matter
+    raw, lab, ln = _device_batch(zh3, lines, widths=widths)
+    for w in sorted(set(widths)):
+        sel = [i for i, ww in enumerate(widths) if ww == w]
+        r2, l2, n2 = _device_batch(zh3, np.ascontiguousarray(lines[sel][:, :, :w]))
+        T = w // 4 + 1
+        for k, i in enumerate(sel):
+            assert np.array_equal(raw[i, :T], r2[k]), (w, i)
+            assert ln[i] == n2[k] and np.array_equal(lab[i, :ln[i]], l2[k, :n2[k]])
+
+
+def test_two_threads_share_one_handle(golden, zh3):
+    """gunicorn runs 2 threads per worker on one model object (gunicorn.conf.py:24)."""
+    G, M = golden
+    crops = [G["inv/%s/bgr" % it["name"]] for it in M["invoice"]]
+    want = [it["zh"] for it in M["invoice"]]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                for c, w in list(zip(crops, want))[k::2]:
+                    assert zh3.ocr(c) == w
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
+def test_error_codes_through_the_abi(zh3):
+    from ocr_amd.crnn import _capi
+    lib = _capi.lib()
+    h = zh3._h
+    a = np.zeros((32, 40), np.uint8)
+    il = _capi.ImageList([a])
+    lab = np.zeros((1, 4), np.int32)
+    ln = np.zeros(1, np.int32)
+    # tmax too small for T = 11
+    rc = lib.crnn_predict_batch(h, il.ptrs, il.h, il.w, il.stride, il.ch, 1, 0, 4, None, lab.ctypes.data,
+                                ln.ctypes.data, None, None)
+    assert rc == _capi.CRNN_ERR_ARG and b"tmax" in lib.crnn_last_error(h)
+    # 2 channels
+    il.ch[0] = 2
+    rc = lib.crnn_predict_batch(h, il.ptrs, il.h, il.w, il.stride, il.ch, 1, 0, 16, None, lab.ctypes.data,
+                                ln.ctypes.data, None, None)
+    assert rc == _capi.CRNN_ERR_ARG
+    # device entry point: width below 8, null pointers
+    assert lib.crnn_forward_device(h, None, 1, 280, None, None, None, None, 1) == _capi.CRNN_ERR_ARG
+    assert lib.crnn_forward_device(h, 1 << 20, 1, 4, None, None, 1 << 20, 1 << 20, 1) == _capi.CRNN_ERR_ARG
+    # weights not loaded
+    from ocr_amd.crnn.network_hip import CRNN
+    empty = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish)
+    with pytest.raises(_capi.CrnnError):
+        empty.ocr(np.zeros((32, 100, 3), np.uint8))
+    # preprocess works without weights (it needs none)
+    assert empty.preprocess([np.zeros((32, 100), np.uint8)])[0].shape == (32, 100)
+
+
+def _child(q, sd_small):
+    try:
+        import numpy as np
+        from ocr_amd.crnn import keys
+        from ocr_amd.crnn.network_hip import CRNN
+        q.put("ok")
+    except Exception as e:  # noqa: BLE001
+        q.put(repr(e))
+
+
+def test_model_built_before_fork_is_usable_in_the_child(synth_en):
+    """gunicorn preload_app (gunicorn.conf.py:57): the model object is built and its weights are
+    loaded in the master BEFORE any HIP call; the forked worker initialises the device on first use.
+    (The parent must not have touched the GPU: run in a fresh interpreter.)"""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from ocr_amd.crnn import keys
+from ocr_amd.crnn.network_hip import CRNN
+from ocr_amd.crnn.synth import synth_state_dict
+m = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish)
+m.load_state_dict(synth_state_dict(65, seed=0))          # host only: no HIP call yet
+rs = np.random.RandomState(0)
+img = rs.randint(0, 256, size=(32, 200, 3)).astype(np.uint8)
+r, w = os.pipe()
+pid = os.fork()
+if pid == 0:
+    os.close(r)
+    try:
+        os.write(w, ("C:" + m.ocr(img)).encode())
+    except Exception as e:
+        os.write(w, ("E:" + repr(e)).encode())
+    os._exit(0)
+os.close(w)
+child = os.read(r, 4096).decode()
+os.waitpid(pid, 0)
+parent = m.ocr(img)                                       # the parent initialises its own context afterwards
+print(child)
+print("P:" + parent)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=110)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and len(lines) == 2, (out.stdout, out.stderr[-2000:])
+    assert lines[0].startswith("C:") and lines[1].startswith("P:"), lines
+    assert lines[0][2:] == lines[1][2:] and len(lines[0]) > 2
