@@ -85,6 +85,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "BENCH_FORCE_DEVICE" in os.environ:      # rehearsal of the N>1 path on a one-GPU box
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
