@@ -193,8 +193,8 @@ def main():
     peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     lines_total = BATCH * args.steps * world
     value = lines_total / elapsed
-    gemm_names = [n for n in order if n.startswith("conv") and n != "conv0_pool0" or n in
-                  ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
+    gemm_names = [n for n in order if (n.startswith("conv") and n != "conv0_pool0" and not n.endswith(("_win", "_wout")))
+                  or n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
     g_ms = sum(acc[n][0] for n in gemm_names)
     g_fl = sum(acc[n][1] for n in gemm_names)
     achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
@@ -234,8 +234,11 @@ def main():
             "algorithmic_bytes_per_launch_avg": sum(acc[n][2] for n in gemm_names) / max(1, len(gemm_names)),
             "flops_per_launch_avg": g_fl / max(1, len(gemm_names)),
             "ms_per_launch_avg": round(g_ms / max(1, len(gemm_names)), 4)},
+        # direct-form algorithmic FLOPs (4.283 GFLOP per line) x lines/s.  The fp32 path runs
+        # conv3-5 as Winograd F(2x2,3x3) (2.25x fewer multiplies), so this "effective" rate can approach
+        # or pass the MFMA peak; roofline.achieved above counts the FLOPs the MFMAs actually execute.
         "pipeline_tflops": round(FLOP_PER_LINE * value / 1e12, 2),
-        "pipeline_frac_of_mfma_peak": round(FLOP_PER_LINE * value / 1e12 / (peak * world), 4),
+        "pipeline_effective_frac_of_mfma_peak": round(FLOP_PER_LINE * value / 1e12 / (peak * world), 4),
         "kernels": kernels,
     }
     if not args.no_cpu_baseline:

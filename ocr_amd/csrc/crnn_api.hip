@@ -67,6 +67,9 @@ struct crnn_handle {
   std::vector<float> h_conv_w[7], h_conv_b[7];
   std::vector<float> h_wih[2], h_bih[2], h_whhp[2], h_emb_w[2], h_emb_b[2], h_lin_w, h_lin_b;
   float lut[256];
+  // Winograd F(2x2,3x3) weights U[16][Cout][Cin] for the layers in wino_mask (fp32 path only)
+  std::vector<float> h_wino[7];
+  unsigned wino_mask = 0;
   // bf16 copies (precision == CRNN_BF16): conv1..6, W_ih, embeddings / linear, packed W_hh
   std::vector<uint16_t> hb_conv_w[7], hb_wih[2], hb_whhp[2], hb_emb_w[2], hb_lin_w;
 
@@ -83,6 +86,8 @@ struct crnn_handle {
   float* d_emb_b[2] = {};
   float* d_lin_w = nullptr;
   float* d_lin_b = nullptr;
+  float* d_wino[7] = {};
+  float* d_zero_bias = nullptr;   // 512 zeros: the Winograd GEMMs add the bias in the output transform
   uint16_t* db_conv_w[7] = {};
   uint16_t* db_wih[2] = {};
   uint16_t* db_whhp[2] = {};
@@ -172,6 +177,8 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       for (int i = 0; i <= MAXK; i++) HIPCHK(h, hipEventCreate(&L.kev[i]));
     }
     upload_norm_lut(h->lut, h->cur->stream);
+    HIPCHK(h, hipMalloc((void**)&h->d_zero_bias, 512 * sizeof(float)));
+    HIPCHK(h, hipMemset(h->d_zero_bias, 0, 512 * sizeof(float)));
     HIPCHK(h, hipStreamSynchronize(h->cur->stream));
     h->dev_pid = getpid();
     h->dev_ready = true;
@@ -195,6 +202,8 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     if ((rc = upload(h, h->h_lin_b, &h->d_lin_b))) return rc;
     for (int i = 0; i < 7; i++)
       if ((rc = upload16(h, h->hb_conv_w[i], &h->db_conv_w[i]))) return rc;
+    for (int i = 0; i < 7; i++)
+      if ((rc = upload(h, h->h_wino[i], &h->d_wino[i]))) return rc;
     for (int l = 0; l < 2; l++) {
       if ((rc = upload16(h, h->hb_wih[l], &h->db_wih[l]))) return rc;
       if ((rc = upload16(h, h->hb_whhp[l], &h->db_whhp[l]))) return rc;
@@ -272,6 +281,7 @@ struct Plan {
   int32_t *wl;   // [8][n] per-layer width arrays
   int32_t *raw;  // [n*T]
   float* pmax;   // [n*T][n-tiles of the classifier]
+  float *wv, *wm; // Winograd V[16][tiles][Cin] and Mo[16][tiles][Cout] (largest enabled layer)
   int32_t* pidx;
   size_t bytes;
 };
@@ -306,6 +316,21 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
   const size_t ntn = ((size_t)h->cfg.nclass + 127) / 128;
   p.pmax = take(n * g.T * ntn);
   p.pidx = (int32_t*)take(n * g.T * ntn);
+  {
+    // tiles and channels of conv1..5: (n*8*ceil(W1/2), 64->128), (n*4*ceil(W2/2), 128->256), (.., 256->256),
+    // (n*2*ceil(W3/2), 256->512), (.., 512->512)
+    const size_t tl[6] = {0, n * 8 * (size_t)((g.W1 + 1) / 2), n * 4 * (size_t)((g.W2 + 1) / 2),
+                          n * 4 * (size_t)((g.W2 + 1) / 2), n * 2 * (size_t)((g.W3 + 1) / 2),
+                          n * 2 * (size_t)((g.W3 + 1) / 2)};
+    size_t vmax = 0, mmax = 0;
+    for (int i = 1; i <= 5; i++)
+      if ((h->wino_mask >> i) & 1u) {
+        vmax = std::max(vmax, 16 * tl[i] * NM[i - 1]);
+        mmax = std::max(mmax, 16 * tl[i] * NM[i]);
+      }
+    p.wv = take(vmax);
+    p.wm = take(mmax);
+  }
   p.bytes = off;
   return p;
 }
@@ -337,9 +362,30 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
 }
 
 void conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
-          int Cin, int Hout, int Wout) {
+          int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   const bool b16 = h->cfg.precision == CRNN_BF16;
+  if (!b16 && ((h->wino_mask >> layer) & 1u) && wino_v) {
+    // Winograd F(2x2,3x3): input transform, 16 batched GEMMs (K = Cin), output transform
+    static const char* wn[3][7] = {{"", "conv1_win", "conv2_win", "conv3_win", "conv4_win", "conv5_win", ""},
+                                   {"", "conv1", "conv2", "conv3", "conv4", "conv5", ""},
+                                   {"", "conv1_wout", "conv2_wout", "conv3_wout", "conv4_wout", "conv5_wout", ""}};
+    const int Co = NM[layer];
+    const long tiles = (long)n * (Hin / 2) * ((Win + 1) / 2);
+    hipStream_t s = h->cur->stream;
+    launch_wino_in((const float*)A, wino_v, n, Hin, Win, Cin, s);
+    kmark(h, wn[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 16.0 * tiles * Cin));
+    ConvGemm q{};
+    q.A = wino_v; q.Wt = h->d_wino[layer]; q.bias = h->d_zero_bias; q.C = wino_m; q.wvalid = nullptr;
+    q.M = (int)tiles; q.N = Co; q.K = Cin; q.ldc = Co;
+    q.Hin = q.Win = q.Hout = q.Wout = 1; q.Cin = Cin; q.ks = 1; q.pad = 0; q.act = 0;
+    q.nbatch = 16; q.bsA = tiles * Cin; q.bsW = (long)Co * Cin; q.bsC = tiles * Co;
+    launch_conv_gemm(q, s);
+    kmark(h, wn[1][layer], 2.0 * 16 * tiles * Co * Cin, 4.0 * 16 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
+    launch_wino_out(wino_m, h->d_conv_b[layer], (float*)C, wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1, s);
+    kmark(h, wn[2][layer], 0, 4.0 * (16.0 * tiles * Co + (double)n * Hin * Win * Co));
+    return;
+  }
   ConvGemm p{};
   p.A = (const float*)A; p.Wt = b16 ? (const float*)h->db_conv_w[layer] : h->d_conv_w[layer];
   p.bias = h->d_conv_b[layer]; p.C = (float*)C; p.wvalid = wvalid;
@@ -382,17 +428,17 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   if (b16) launch_conv0_pool_bf16(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
   else launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
   kmark(h, "conv0_pool0", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * dn * 32 * g.W + es * dn * 16 * g.W1 * 64);
-  conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1);
+  conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1, p.wv, p.wm);
   if (b16) launch_pool_2x2s2_bf16(p.c1, p.p1, n, 16, g.W1, 128, s);
   else launch_pool_2x2s2(p.c1, p.p1, n, 16, g.W1, 128, s);
   kmark(h, "pool1", 0, es * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
-  conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2);
-  conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2);
+  conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2, p.wv, p.wm);
+  conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2, p.wv, p.wm);
   if (b16) launch_pool_2x2s21p01_bf16(p.c3, p.p2, n, 8, g.W2, 256, s);
   else launch_pool_2x2s21p01(p.c3, p.p2, n, 8, g.W2, 256, s);
   kmark(h, "pool2", 0, es * (dn * 8 * g.W2 * 256 + dn * 4 * g.W3 * 256));
-  conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3);
-  conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3);
+  conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3, p.wv, p.wm);
+  conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3, p.wv, p.wm);
   if (b16) launch_pool_2x2s21p01_bf16(p.c5, p.p3, n, 4, g.W3, 512, s);
   else launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
   kmark(h, "pool3", 0, es * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
@@ -542,6 +588,9 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   if (!h) return CRNN_ERR_NOMEM;
   h->cfg = *cfg;
   h->nlanes = cfg->lanes <= 0 ? 1 : (cfg->lanes > MAX_LANES ? MAX_LANES : cfg->lanes);
+  // Winograd layers (bit i = conv i, i in 1..5): default conv3..5 (measured best); CRNN_WINOGRAD=<mask> overrides (0 = off)
+  h->wino_mask = cfg->precision == CRNN_FP32 ? 0x38u : 0u;
+  if (const char* e = getenv("CRNN_WINOGRAD")) h->wino_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
   for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);
   *out = h;
   return 0;
@@ -607,6 +656,35 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
               }
             }
           }
+    }
+  }
+  // Winograd weights: U = G g G^T per (co, ci), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], BN folded first
+  for (int i = 1; i <= 5; i++) {
+    if (!((h->wino_mask >> i) & 1u)) continue;
+    const int cin = NM[i - 1], co = NM[i];
+    const std::string pc = "cnn.conv" + std::to_string(i) + ".";
+    const float* w = m[pc + "weight"]->data;
+    const float *g = nullptr, *var = nullptr;
+    if (HAS_BN[i]) {
+      const std::string pb = "cnn.batchnorm" + std::to_string(i) + ".";
+      g = m[pb + "weight"]->data;
+      var = m[pb + "running_var"]->data;
+    }
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    h->h_wino[i].assign((size_t)16 * co * cin, 0.f);
+    for (int o = 0; o < co; o++) {
+      const double sc = g ? (double)g[o] / std::sqrt((double)var[o] + 1e-5) : 1.0;
+      for (int c = 0; c < cin; c++) {
+        double gg[3][3], t[4][3];
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) gg[a][b] = (double)w[(((size_t)o * cin + c) * 3 + a) * 3 + b] * sc;
+        for (int a = 0; a < 4; a++)
+          for (int b = 0; b < 3; b++) t[a][b] = G[a][0] * gg[0][b] + G[a][1] * gg[1][b] + G[a][2] * gg[2][b];
+        for (int a = 0; a < 4; a++)
+          for (int b = 0; b < 4; b++)
+            h->h_wino[i][((size_t)(a * 4 + b) * co + o) * cin + c] =
+                (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+      }
     }
   }
   if (h->cfg.lstm) {
@@ -892,7 +970,8 @@ void crnn_destroy(crnn_handle* h) {
       (void)hipFree(h->d_wih[l]); (void)hipFree(h->d_bih[l]); (void)hipFree(h->d_whhp[l]);
       (void)hipFree(h->d_emb_w[l]); (void)hipFree(h->d_emb_b[l]);
     }
-    (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->db_lin_w);
+    (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->db_lin_w); (void)hipFree(h->d_zero_bias);
+    for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }
     for (int l = 0; l < h->nlanes; l++) {

@@ -25,6 +25,9 @@ struct ConvGemm {
   // C may then be nullptr (no logits written).  launch_argmax_partials finishes the reduction.
   float* pmax;
   int32_t* pidx;
+  // batched GEMM (Winograd: 16 independent GEMMs): blockIdx.y selects the batch; element strides
+  int nbatch;         // 0 or 1 = not batched
+  long bsA, bsW, bsC;
 };
 
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
@@ -75,6 +78,15 @@ __device__ __forceinline__ void argmax_epilogue(const crnn_f32x16 (&acc)[2][2], 
   }
 }
 #endif
+
+// Winograd F(2x2,3x3) for the 3x3 / pad 1 convolutions (fp32): 2.25x fewer MFMA FLOPs than the direct
+// form.  x NHWC [B,H,W,C] (H even) -> V[16][B*(H/2)*ceil(W/2)][C] (input transform B^T d B);
+// 16 batched GEMMs with U[16][Cout][C] (= G g G^T, BatchNorm folded, made at load time) give
+// Mo[16][tiles][Cout]; the output transform A^T m A adds bias, applies the activation and the
+// per-line width mask and writes NHWC [B,H,W,Cout].
+void launch_wino_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s);
+void launch_wino_out(const float* Mo, const float* bias, float* y, const int32_t* wvalid, int B, int H,
+                     int W, int Cout, int act, hipStream_t s);
 
 // conv0 (1->64, 3x3, pad 1) + ReLU + MaxPool 2x2/2, direct (K = 9, HBM-bound).
 // in f32 [B,32,W]; out NHWC [B,16,W/2,64]; w1valid: per-sample valid pooled width or nullptr.

@@ -50,10 +50,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ConvGemm p) {
   // the tap displacement is added through the scalar offset.  Rows beyond M / N are clamped to
   // the last valid row (their results are never stored).
   const long shift = ((long)p.pad * p.Win + p.pad) * p.Cin;
+  const float* Ab = p.A + (long)blockIdx.y * p.bsA;      // batched GEMM: blockIdx.y = batch
+  const float* Wb = p.Wt + (long)blockIdx.y * p.bsW;
+  float* Cb = p.C ? p.C + (long)blockIdx.y * p.bsC : nullptr;
   const __amdgpu_buffer_rsrc_t a_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.A - shift), 0, 0x7FFFFFFF, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)(Ab - shift), 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, 0x7FFFFFFF, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7FFFFFFF, 0x00020000);
   unsigned aoff[4], amask[4], boff[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ConvGemm p) {
   if (p.pmax) {   // fused classifier arg-max (wave-uniform branch)
     __syncthreads();
     argmax_epilogue(acc, p, smem, (int*)(smem + 256), m0, n0, bn, ntn, wm, wn, lane, tid);
-    if (!p.C) return;
+    if (!Cb) return;
   }
 
   // epilogue: bias + activation + per-sample width mask.  C/D map of the 32x32
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ConvGemm p) {
             int x = rr % p.Wout;
             if (x >= p.wvalid[b]) v = 0.f;
           }
-          if (nok) p.C[(long)row * p.ldc + n] = v;
+          if (nok) Cb[(long)row * p.ldc + n] = v;
         }
       }
     }
@@ -183,7 +186,127 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ConvGemm p) {
 
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL(conv_gemm_kernel, dim3(ntm * ntn), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(conv_gemm_kernel, dim3(ntm * ntn, p.nbatch > 1 ? p.nbatch : 1), dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
+// Winograd F(2x2,3x3) transforms (fp32, HBM-bound elementwise kernels; float4 over channels).
+// B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  A^T = [1 1 1 0; 0 1 -1 -1].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                      int B, int H, int W, int C) {
+  const int th = H >> 1, tw = (W + 1) >> 1, C4 = C >> 2;
+  const long ntile = (long)B * th * tw;
+  const long total = ntile * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th);
+    const int b = (int)(r / th);
+    f32x4 d[4][4];
+#pragma unroll
+    for (int dy = 0; dy < 4; dy++) {
+      const int yy = 2 * ty - 1 + dy;
+#pragma unroll
+      for (int dx = 0; dx < 4; dx++) {
+        const int xx = 2 * tx - 1 + dx;
+        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        d[dy][dx] = ok ? *(const f32x4*)(x + (((long)b * H + yy) * W + xx) * C + c4 * 4) : z;
+      }
+    }
+    f32x4 u[4][4];   // B^T d (rows)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      u[0][j] = d[0][j] - d[2][j];
+      u[1][j] = d[1][j] + d[2][j];
+      u[2][j] = d[2][j] - d[1][j];
+      u[3][j] = d[1][j] - d[3][j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {   // (B^T d) B (columns)
+      const f32x4 v0 = u[k][0] - u[k][2];
+      const f32x4 v1 = u[k][1] + u[k][2];
+      const f32x4 v2 = u[k][2] - u[k][1];
+      const f32x4 v3 = u[k][1] - u[k][3];
+      float* o = V + ((long)(k * 4) * ntile + t) * C + c4 * 4;
+      *(f32x4*)(o) = v0;
+      *(f32x4*)(o + ntile * C) = v1;
+      *(f32x4*)(o + 2 * ntile * C) = v2;
+      *(f32x4*)(o + 3 * ntile * C) = v3;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
+                                                       float* __restrict__ y, const int32_t* __restrict__ wvalid,
+                                                       int B, int H, int W, int Co, int act) {
+  const int th = H >> 1, tw = (W + 1) >> 1, C4 = Co >> 2;
+  const long ntile = (long)B * th * tw;
+  const long total = ntile * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th);
+    const int b = (int)(r / th);
+    f32x4 m[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) m[k][j] = *(const f32x4*)(Mo + ((long)(k * 4 + j) * ntile + t) * Co + c4 * 4);
+    f32x4 s0[4], s1[4];   // A^T m
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      s0[j] = m[0][j] + m[1][j] + m[2][j];
+      s1[j] = m[1][j] - m[2][j] - m[3][j];
+    }
+    const f32x4 bs = *(const f32x4*)(bias + c4 * 4);
+    f32x4 o[2][2];
+    o[0][0] = s0[0] + s0[1] + s0[2] + bs;
+    o[0][1] = s0[1] - s0[2] - s0[3] + bs;
+    o[1][0] = s1[0] + s1[1] + s1[2] + bs;
+    o[1][1] = s1[1] - s1[2] - s1[3] + bs;
+    const int wv = wvalid ? wvalid[b] : W;
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 2; dx++) {
+        const int xx = 2 * tx + dx;
+        if (xx >= W) continue;
+        f32x4 v = o[dy][dx];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float e = v[c];
+          if (act == 1) e = e > 0.f ? e : 0.f;
+          else if (act == 2) e = e > 0.f ? e : 0.2f * e;
+          if (xx >= wv) e = 0.f;
+          v[c] = e;
+        }
+        *(f32x4*)(y + (((long)b * H + 2 * ty + dy) * W + xx) * Co + c4 * 4) = v;
+      }
+  }
+}
+
+static unsigned ew_blocks_w(long total) {
+  long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+void launch_wino_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s) {
+  const long total = (long)B * (H / 2) * ((W + 1) / 2) * (C / 4);
+  hipLaunchKernelGGL(wino_in_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, x, V, B, H, W, C);
+}
+void launch_wino_out(const float* Mo, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
+                     int Cout, int act, hipStream_t s) {
+  const long total = (long)B * (H / 2) * ((W + 1) / 2) * (Cout / 4);
+  hipLaunchKernelGGL(wino_out_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, Mo, bias, y, wvalid, B, H, W,
+                     Cout, act);
 }
 
 // ---------------------------------------------------------------------------

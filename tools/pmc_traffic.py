@@ -4,8 +4,13 @@ wide coalesced streaming read (double it); WRITE_SIZE is exact for 16-byte strea
 counters are in KiB.  Launches of one step are identified by their order inside the step."""
 import csv, glob, sys, collections, json
 
-ORDER = ["normalize", "conv0_pool0", "conv1", "pool1", "conv2", "conv3", "pool2", "conv4", "conv5", "pool3",
-         "conv6", "lstm0_ih", "lstm0_rec", "emb0", "lstm1_ih", "lstm1_rec", "classifier", "argmax", "ctc"]
+ORDER_DIRECT = ["normalize", "conv0_pool0", "conv1", "pool1", "conv2", "conv3", "pool2", "conv4", "conv5", "pool3",
+                "conv6", "lstm0_ih", "lstm0_rec", "emb0", "lstm1_ih", "lstm1_rec", "classifier", "argmax", "ctc"]
+# fp32 default: conv3..5 as Winograd (input transform, batched GEMM, output transform)
+ORDER_WINO = ["normalize", "conv0_pool0", "conv1", "pool1", "conv2", "conv3_win", "conv3", "conv3_wout", "pool2",
+              "conv4_win", "conv4", "conv4_wout", "conv5_win", "conv5", "conv5_wout", "pool3",
+              "conv6", "lstm0_ih", "lstm0_rec", "emb0", "lstm1_ih", "lstm1_rec", "classifier", "argmax", "ctc"]
+ORDER = ORDER_WINO if (len(sys.argv) > 4 and sys.argv[4] == "wino") else ORDER_DIRECT
 
 
 def per_launch(d, counter):
