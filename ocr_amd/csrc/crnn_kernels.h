@@ -77,6 +77,62 @@ __device__ __forceinline__ void argmax_epilogue(const crnn_f32x16 (&acc)[2][2], 
     p.pidx[(long)(m0 + tid) * ntn + bn] = takeb ? si[128 + tid] : si[tid];
   }
 }
+
+// Store epilogue shared by the fp32 and bf16 GEMM kernels: bias + activation (+ per-line width
+// mask) for the wave's 2x2 accumulator tiles.  The activation is a pair of selects, the row guard
+// and the mask are computed once per row, and the masked variant is a separate (wave-uniform) path.
+template <bool OUT_BF16>
+__device__ __forceinline__ void store_epilogue(const crnn_f32x16 (&acc)[2][2], const ConvGemm& p, float* Cb, int m0,
+                                               int n0, int wm, int wn, int lane) {
+  const int act = p.act;
+  auto activate = [&](float v) {   // same selects as torch: x > 0 ? x : (0 | 0.2 x); act 0 = identity
+    const float neg = act == 2 ? 0.2f * v : (act == 1 ? 0.f : v);
+    return v > 0.f ? v : neg;
+  };
+  const int c0 = n0 + wn * 64 + (lane & 31), c1 = c0 + 32;
+  const bool ok0 = c0 < p.N, ok1 = c1 < p.N;
+  const float b0 = ok0 ? p.bias[c0] : 0.f, b1 = ok1 ? p.bias[c1] : 0.f;
+  const int hw = p.Hout * p.Wout;
+  const int rbase = m0 + wm * 64 + 4 * (lane >> 5);
+  auto put = [&](long off, float v, bool ok) {
+    if (!ok) return;
+    if (OUT_BF16) ((__bf16*)Cb)[off] = (__bf16)v;
+    else Cb[off] = v;
+  };
+  if (!p.wvalid) {
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+        const bool rok = row < p.M;
+        const long off = (long)row * p.ldc;
+        float v0 = acc[mt][0][r] + b0, v1 = acc[mt][1][r] + b1;
+        v0 = activate(v0);
+        v1 = activate(v1);
+        put(off + c0, v0, rok && ok0);
+        put(off + c1, v1, rok && ok1);
+      }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+        const bool rok = row < p.M;
+        const int rr = rok ? row : 0;
+        const int b = rr / hw;
+        const int x = (rr - b * hw) % p.Wout;
+        const bool keep = x < p.wvalid[b];
+        const long off = (long)row * p.ldc;
+        float v0 = acc[mt][0][r] + b0, v1 = acc[mt][1][r] + b1;
+        v0 = keep ? activate(v0) : 0.f;
+        v1 = keep ? activate(v1) : 0.f;
+        put(off + c0, v0, rok && ok0);
+        put(off + c1, v1, rok && ok1);
+      }
+  }
+}
 #endif
 
 // Winograd F(2x2,3x3) for the 3x3 / pad 1 convolutions (fp32): 2.25x fewer MFMA FLOPs than the direct

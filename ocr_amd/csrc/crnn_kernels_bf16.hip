@@ -131,33 +131,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16_kernel(const ConvGemm p
     if (!p.C) return;
   }
 
-#pragma unroll
-  for (int nt = 0; nt < 2; nt++) {
-    const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
-    const bool nok = n < p.N;
-    const float bias = nok ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = acc[mt][nt][r] + bias;
-        if (p.act == 1) v = v > 0.f ? v : 0.f;
-        else if (p.act == 2) v = v > 0.f ? v : 0.2f * v;
-        if (row < p.M) {
-          if (p.wvalid) {
-            int b = row / hw, rr = row - b * hw;
-            int x = rr % p.Wout;
-            if (x >= p.wvalid[b]) v = 0.f;
-          }
-          if (nok) {
-            if (OUT_BF16) ((__bf16*)p.C)[(long)row * p.ldc + n] = (__bf16)v;
-            else p.C[(long)row * p.ldc + n] = v;
-          }
-        }
-      }
-    }
-  }
+  store_epilogue<OUT_BF16>(acc, p, p.C, m0, n0, wm, wn, lane);
 }
 
 void launch_conv_gemm_bf16(const ConvGemm& p, bool out_bf16, hipStream_t s) {

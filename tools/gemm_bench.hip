@@ -184,6 +184,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
   const int bm = blockIdx.x / ntn, bn = blockIdx.x - bm * ntn;
   const int m0 = bm * BM, n0 = bn * BN;
   const int lrow = tid >> 3, lk = (tid & 7) * 4;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  if (EPI == 5) t0 = __builtin_amdgcn_s_memtime();
   const int hw = p.Hout * p.Wout;
   // descriptor bases: A shifted back by the padding so that every voffset is >= 0
   const long shift = ((long)p.pad * p.Win + p.pad) * p.Cin;
@@ -207,6 +209,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
     int n = n0 + lrow + 32 * i;
     n = n < p.N ? n : p.N - 1;
     boff[i] = (unsigned)(((long)n * p.K + lk) * 4);
+  }
+  if (EPI == 3 && blockIdx.x < 1024) {
+    // stagger: co-resident blocks (ids b, b+256, b+512, b+768 share a CU under round-robin placement)
+    const int slot = blockIdx.x >> 8;
+    for (int i = 0; i < slot * (p.K / BK_) / 2; i++) __builtin_amdgcn_s_sleep(127);   // ~ slot * tile_time/4
   }
   const int nk = p.K / BK_;
   f32x4 ra[NP], rb[NP];
@@ -261,6 +268,45 @@ __global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
       }
     }
   };
+  if (EPI == 5) t1 = __builtin_amdgcn_s_memtime();
+  if (EPI == 4) {
+    // prefetch distance 2: tiles kt+1 (set B) and kt+2 (set A) in flight while computing kt
+    f32x4 ra2[NP], rb2[NP];
+    auto gload2 = [&]() {
+      const int toff = ((l_ky * p.Win + l_kx) * p.Cin + l_ci) * 4;
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        const unsigned vo = ((amask[i] >> l_tap) & 1u) ? aoff[i] : 0x80000000u;
+        ra2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, vo, toff, 0));
+        rb2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, boff[i], l_k0 * 4, 0));
+      }
+      l_k0 += BK_; l_ci += BK_;
+      const bool wrap_c = l_ci == p.Cin;
+      l_ci = wrap_c ? 0 : l_ci; l_tap += wrap_c ? 1 : 0; l_kx += wrap_c ? 1 : 0;
+      const bool wrap_x = l_kx == p.ks;
+      l_kx = wrap_x ? 0 : l_kx; l_ky += wrap_x ? 1 : 0;
+    };
+    auto sstore2 = [&]() {
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        *(f32x4*)(smem + (lrow + 32 * i) * LDT + lk) = ra2[i];
+        *(f32x4*)(smem + BM * LDT + (lrow + 32 * i) * LDT + lk) = rb2[i];
+      }
+    };
+    // nk is even for all our shapes here (K multiple of 64)
+    gload(); sstore(0); gload2(); __syncthreads();      // tile0 in LDS, tile1 in set 2
+    for (int kt = 0; kt < nk - 2; kt += 2) {
+      gload();                 // tile kt+2 -> set 1
+      compute(0);              // tile kt
+      __syncthreads(); sstore2(); __syncthreads();       // tile kt+1 -> LDS
+      gload2();                // tile kt+3 -> set 2
+      compute(0);              // tile kt+1
+      __syncthreads(); sstore(0); __syncthreads();       // tile kt+2 -> LDS
+    }
+    compute(0);                // tile nk-2
+    __syncthreads(); sstore2(); __syncthreads();
+    compute(0);                // tile nk-1
+  } else
   if (NBUF == 2) {
     gload(); sstore(0); __syncthreads();
     for (int kt = 0; kt < nk - 1; kt++) {
@@ -275,6 +321,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
     }
     compute(0);
   }
+  if (EPI == 5) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][1])); t2 = __builtin_amdgcn_s_memtime(); }
   if (EPI == 1) {
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -327,6 +374,14 @@ __global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
         if (row < p.M && nok) p.C[(long)row * p.ldc + n] = v;
       }
   }
+  if (EPI == 5) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t3 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+      unsigned long long* st = (unsigned long long*)p.wvalid + (size_t)blockIdx.x * 4;
+      st[0] = t0; st[1] = t1; st[2] = t2; st[3] = t3;
+    }
+  }
 }
 
 template <typename F>
@@ -356,9 +411,10 @@ int main(int argc, char** argv) {
     case 5: p.Hin = 4;  p.Win = 71;  p.Cin = 512; p.Hout = 4;  p.Wout = 71;  p.N = 512; p.ks = 3; p.pad = 1; break;
     case 6: p.Hin = 2;  p.Win = 72;  p.Cin = 512; p.Hout = 1;  p.Wout = 71;  p.N = 512; p.ks = 2; p.pad = 0; break;
     case 7: p.Hin = 1;  p.Win = 1;   p.Cin = 512; p.Hout = 1;  p.Wout = 1;   p.N = 5530; p.ks = 1; p.pad = 0; break;
+    case 9: p.Hin = 1;  p.Win = 1;   p.Cin = 256; p.Hout = 1;  p.Wout = 1;   p.N = 256; p.ks = 1; p.pad = 0; break;
     default: p.Hin = 1; p.Win = 1;   p.Cin = 512; p.Hout = 1;  p.Wout = 1;   p.N = 2048; p.ks = 1; p.pad = 0; break;
   }
-  const long nb = (layer >= 7) ? (long)B * 71 : B;
+  const long nb = (layer == 9) ? 16L * 35840 : (layer >= 7) ? (long)B * 71 : B;
   p.M = (int)(nb * p.Hout * p.Wout); p.K = p.ks * p.ks * p.Cin; p.ldc = p.N; p.act = 1;
   const size_t na = (size_t)nb * p.Hin * p.Win * p.Cin, nw = (size_t)p.N * p.K, nc = (size_t)p.M * p.N;
   std::vector<float> hA(na), hW(nw), hb(p.N);
@@ -418,8 +474,19 @@ int main(int argc, char** argv) {
     RUN("bk32 nbuf2 (current)", 32, 2, 0, 2);
     RUN("bk32 nbuf1 minw3", 32, 1, 0, 3);
     RUNB("buffer loads nbuf1 minw3", 1, 3);
-    RUNB("  + no stores", 1, 3, 1);
-    RUNB("  + LDS-transposed f4 stores", 1, 3, 2);
+    if (rep == 0) {
+      unsigned long long* dst; CK(hipMalloc(&dst, (size_t)grid * 32));
+      p.wvalid = (const int*)dst;
+      hipLaunchKernelGGL((gemm_b<1, 3, 5>), dim3(grid), dim3(256), 0, 0, p); CK(hipDeviceSynchronize());
+      hipLaunchKernelGGL((gemm_b<1, 3, 5>), dim3(grid), dim3(256), 0, 0, p); CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> st((size_t)grid * 4);
+      CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
+      double a = 0, b = 0, c = 0; unsigned long long tmin = ~0ull, tmax = 0;
+      for (int i = 0; i < grid; i++) { a += st[i*4+1]-st[i*4]; b += st[i*4+2]-st[i*4+1]; c += st[i*4+3]-st[i*4+2];
+        if (st[i*4] < tmin) tmin = st[i*4]; if (st[i*4+3] > tmax) tmax = st[i*4+3]; }
+      printf("stamps (s_memtime ticks, 100 MHz?): prologue %.0f  loop %.0f  epilogue %.0f  per block; kernel span %llu\n", a / grid, b / grid, c / grid, tmax - tmin);
+      p.wvalid = nullptr;
+    }
     for (int ns = 2; ns <= 1; ns++) {
       hipStream_t st[3];
       for (int i = 0; i < ns; i++) CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
