@@ -70,6 +70,7 @@ struct crnn_handle {
   // Winograd F(2x2,3x3) weights U[16][Cout][Cin] for the layers in wino_mask (fp32 path only)
   std::vector<float> h_wino[7];
   unsigned wino_mask = 0;
+  bool wino_fused = true;   // GEMM + output transform in one kernel (CRNN_WINO_FUSED=0: separate kernels)
   // bf16 copies (precision == CRNN_BF16): conv1..6, W_ih, embeddings / linear, packed W_hh
   std::vector<uint16_t> hb_conv_w[7], hb_wih[2], hb_whhp[2], hb_emb_w[2], hb_lin_w;
 
@@ -326,7 +327,7 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
     for (int i = 1; i <= 5; i++)
       if ((h->wino_mask >> i) & 1u) {
         vmax = std::max(vmax, 16 * tl[i] * NM[i - 1]);
-        mmax = std::max(mmax, 16 * tl[i] * NM[i]);
+        if (!h->wino_fused) mmax = std::max(mmax, 16 * tl[i] * NM[i]);
       }
     p.wv = take(vmax);
     p.wm = take(mmax);
@@ -361,8 +362,10 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
         es * ((double)M * K + (double)N * K) + (C ? ((b16 && out_bf16) ? 2.0 : 4.0) * M * N : 8.0 * M * ((N + 127) / 128)));
 }
 
-void conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
-          int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr) {
+// pool_out: where a following MaxPool 2x2/2 would write; the fused Winograd kernel can apply it
+// itself (one tile == one pool window).  Returns true when it did, so the caller skips the pool.
+bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
+          int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr, float* pool_out = nullptr) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   const bool b16 = h->cfg.precision == CRNN_BF16;
   if (!b16 && ((h->wino_mask >> layer) & 1u) && wino_v) {
@@ -375,6 +378,18 @@ void conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     hipStream_t s = h->cur->stream;
     launch_wino_in((const float*)A, wino_v, n, Hin, Win, Cin, s);
     kmark(h, wn[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 16.0 * tiles * Cin));
+    if (h->wino_fused) {
+      WinoGemm w{};
+      w.V = wino_v; w.U = h->d_wino[layer]; w.bias = h->d_conv_b[layer]; w.y = (float*)C; w.wvalid = wvalid;
+      w.ntile = (int)tiles; w.N = Co; w.Cin = Cin; w.B = n; w.H = Hin; w.W = Win;
+      w.act = h->cfg.leaky_relu ? 2 : 1; w.pool = pool_out ? 1 : 0;
+      if (pool_out) w.y = pool_out;
+      launch_wino_gemm(w, s);
+      kmark(h, pool_out ? "conv1_pool1" : wn[1][layer], 2.0 * 16 * tiles * Co * Cin,
+            4.0 * (16.0 * tiles * Cin + 16.0 * Co * Cin +
+                   (pool_out ? (double)n * (Hin / 2) * (Win / 2) : (double)n * Hin * Win) * Co));
+      return pool_out != nullptr;
+    }
     ConvGemm q{};
     q.A = wino_v; q.Wt = h->d_wino[layer]; q.bias = h->d_zero_bias; q.C = wino_m; q.wvalid = nullptr;
     q.M = (int)tiles; q.N = Co; q.K = Cin; q.ldc = Co;
@@ -384,7 +399,7 @@ void conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     kmark(h, wn[1][layer], 2.0 * 16 * tiles * Co * Cin, 4.0 * 16 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
     launch_wino_out(wino_m, h->d_conv_b[layer], (float*)C, wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1, s);
     kmark(h, wn[2][layer], 0, 4.0 * (16.0 * tiles * Co + (double)n * Hin * Win * Co));
-    return;
+    return false;
   }
   ConvGemm p{};
   p.A = (const float*)A; p.Wt = b16 ? (const float*)h->db_conv_w[layer] : h->d_conv_w[layer];
@@ -398,6 +413,7 @@ void conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
   const double es = b16 ? 2.0 : 4.0;
   kmark(h, names[layer], 2.0 * p.M * p.N * p.K,
         es * ((double)n * Hin * Win * Cin + (double)p.N * p.K + (double)p.M * p.N));
+  return false;
 }
 
 // Runs the network on the normalised input already in plan.x.  widths: host
@@ -428,10 +444,11 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   if (b16) launch_conv0_pool_bf16(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
   else launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
   kmark(h, "conv0_pool0", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * dn * 32 * g.W + es * dn * 16 * g.W1 * 64);
-  conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1, p.wv, p.wm);
-  if (b16) launch_pool_2x2s2_bf16(p.c1, p.p1, n, 16, g.W1, 128, s);
-  else launch_pool_2x2s2(p.c1, p.p1, n, 16, g.W1, 128, s);
-  kmark(h, "pool1", 0, es * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
+  if (!conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1, p.wv, p.wm, p.p1)) {
+    if (b16) launch_pool_2x2s2_bf16(p.c1, p.p1, n, 16, g.W1, 128, s);
+    else launch_pool_2x2s2(p.c1, p.p1, n, 16, g.W1, 128, s);
+    kmark(h, "pool1", 0, es * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
+  }
   conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2, p.wv, p.wm);
   conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2, p.wv, p.wm);
   if (b16) launch_pool_2x2s21p01_bf16(p.c3, p.p2, n, 8, g.W2, 256, s);
@@ -589,7 +606,8 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   h->cfg = *cfg;
   h->nlanes = cfg->lanes <= 0 ? 1 : (cfg->lanes > MAX_LANES ? MAX_LANES : cfg->lanes);
   // Winograd layers (bit i = conv i, i in 1..5): default conv3..5 (measured best); CRNN_WINOGRAD=<mask> overrides (0 = off)
-  h->wino_mask = cfg->precision == CRNN_FP32 ? 0x38u : 0u;
+  h->wino_mask = cfg->precision == CRNN_FP32 ? 0x3Eu : 0u;
+  if (const char* e = getenv("CRNN_WINO_FUSED")) h->wino_fused = atoi(e) != 0;
   if (const char* e = getenv("CRNN_WINOGRAD")) h->wino_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
   for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);
   *out = h;

@@ -144,6 +144,22 @@ void launch_wino_in(const float* x, float* V, int B, int H, int W, int C, hipStr
 void launch_wino_out(const float* Mo, const float* bias, float* y, const int32_t* wvalid, int B, int H,
                      int W, int Cout, int act, hipStream_t s);
 
+// Fused form of the two steps above: one block owns 128 tiles x 64 output channels, runs the 16
+// component GEMMs back to back (an effective K of 16*Cin, so short-K layers keep the MFMA pipe
+// full), folds each product into the four 2x2 outputs in registers (A^T m A has only 0/+-1
+// coefficients) and writes bias + activation + mask straight to NHWC -- Mo never exists.
+// pool = 1 additionally takes the max over the 2x2 tile (MaxPool 2x2/2 == one Winograd tile) and
+// writes [B,H/2,W/2,N] (W even).  Requires N % 64 == 0, Cin % 32 == 0, H even.
+struct WinoGemm {
+  const float* V;         // [16][ntile][Cin]
+  const float* U;         // [16][N][Cin]
+  const float* bias;      // [N]
+  float* y;               // NHWC [B,H,W,N]  (pool: [B,H/2,W/2,N])
+  const int32_t* wvalid;  // per-line valid output width (pre-pool columns) or nullptr
+  int ntile, N, Cin, B, H, W, act, pool;
+};
+void launch_wino_gemm(const WinoGemm& p, hipStream_t s);
+
 // conv0 (1->64, 3x3, pad 1) + ReLU + MaxPool 2x2/2, direct (K = 9, HBM-bound).
 // in f32 [B,32,W]; out NHWC [B,16,W/2,64]; w1valid: per-sample valid pooled width or nullptr.
 void launch_conv0_pool(const float* in, const float* w9x64, const float* bias, float* out,

@@ -266,6 +266,195 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fused Winograd GEMM + output transform.  Block = 128 tiles x 64 channels, 4 waves as 2(M) x 2(N),
+// wave tile 64 x 32 (two 32x32 MFMA tiles); per wave 32 product registers + 4 x 32 output
+// registers, so two blocks share a CU.  LDS is double buffered (one barrier per K step of 32).
+// The 16 components run as one flat loop of 16 * Cin/32 steps; the loader runs one step ahead and
+// simply walks into the next component.  After the last K step of component (a,b) the product is
+// added into output (i,j) with coefficient AT[i][a] * AT[j][b] (0 / +-1, exact as an fma).
+// Block order: hardware deals consecutive block ids round-robin over the 8 XCDs, so the logical
+// tile id is (id % 8) * chunk + id / 8 -- the N-blocks that share a V tile then sit on one XCD's L2.
+// ---------------------------------------------------------------------------
+constexpr int WBM = 128, WBN = 64, WBUF = (WBM + WBN) * LDT;
+
+__global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * WBUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = p.N / WBN;
+  const int nblk = ((p.ntile + WBM - 1) / WBM) * ntn;
+  const int chunk = gridDim.x >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= nblk) return;
+  const int bm = L / ntn, bn = L - bm * ntn;
+  const int m0 = bm * WBM, n0 = bn * WBN;
+  const int lrow = tid >> 3, lk = (tid & 7) * 4;
+
+  unsigned aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int m = m0 + lrow + 32 * i;
+    m = m < p.ntile ? m : p.ntile - 1;
+    aoff[i] = (unsigned)(((long)m * p.Cin + lk) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) boff[i] = (unsigned)(((long)(n0 + lrow + 32 * i) * p.Cin + lk) * 4);
+  const long bsA = (long)p.ntile * p.Cin, bsW = (long)p.N * p.Cin;
+  const int nk = p.Cin / BK;
+
+  // two register sets: the loader runs two K steps ahead (one step of MFMAs per wave is only
+  // ~2 us at two waves per SIMD, not enough to cover an HBM miss)
+  f32x4 ra[2][4], rb[2][2];
+  int l_comp = 0, l_k0 = 0;   // position of the next K step to load (wave uniform)
+  auto gload = [&](int set) {
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + l_comp * bsA), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.U + l_comp * bsW), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      ra[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, aoff[i], l_k0 * 4, 0));
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      rb[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, boff[i], l_k0 * 4, 0));
+    l_k0 += BK;
+    const bool wrap = l_k0 == p.Cin;
+    l_k0 = wrap ? 0 : l_k0;
+    l_comp += wrap ? 1 : 0;
+  };
+  auto sstore = [&](int set, int buf) {
+    float* sa = smem + buf * WBUF;
+    float* sb = sa + WBM * LDT;
+#pragma unroll
+    for (int i = 0; i < 4; i++) *(f32x4*)(sa + (lrow + 32 * i) * LDT + lk) = ra[set][i];
+#pragma unroll
+    for (int i = 0; i < 2; i++) *(f32x4*)(sb + (lrow + 32 * i) * LDT + lk) = rb[set][i];
+  };
+
+  f32x16 acc[2], o[2][2][2];   // o[i][j][mt]: output (2ty+i, 2tx+j) of the tiles in MFMA tile mt
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    acc[0][r] = 0.f; acc[1][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) { o[i][j][0][r] = 0.f; o[i][j][1][r] = 0.f; }
+  }
+  // fragments of k-group g+1 are read while the 8 MFMAs of k-group g run (two fragment sets)
+  auto compute = [&](int buf) {
+    const float* a = smem + buf * WBUF + (wm * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
+    const float* b = smem + buf * WBUF + WBM * LDT + (wn * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
+    f32x4 a0[2], a1[2], b0[2];
+    a0[0] = *(const f32x4*)(a);
+    a1[0] = *(const f32x4*)(a + 32 * LDT);
+    b0[0] = *(const f32x4*)(b);
+#pragma unroll
+    for (int kg = 0; kg < 4; kg++) {
+      const int c = kg & 1;
+      if (kg < 3) {
+        a0[c ^ 1] = *(const f32x4*)(a + (kg + 1) * 8);
+        a1[c ^ 1] = *(const f32x4*)(a + 32 * LDT + (kg + 1) * 8);
+        b0[c ^ 1] = *(const f32x4*)(b + (kg + 1) * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c][j], b0[c][j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c][j], b0[c][j], acc[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  int kc = 0, comp = 0;
+  auto flush = [&]() {   // component (a,b) complete: o[i][j] += AT[i][a] * AT[j][b] * acc
+    const int ka = comp >> 2, kb = comp & 3;
+    const float ra0 = ka < 3 ? 1.f : 0.f, ra1 = ka == 0 ? 0.f : (ka == 1 ? 1.f : -1.f);
+    const float cb0 = kb < 3 ? 1.f : 0.f, cb1 = kb == 0 ? 0.f : (kb == 1 ? 1.f : -1.f);
+    const float c00 = ra0 * cb0, c01 = ra0 * cb1, c10 = ra1 * cb0, c11 = ra1 * cb1;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float v = acc[mt][r];
+        o[0][0][mt][r] = __builtin_fmaf(c00, v, o[0][0][mt][r]);
+        o[0][1][mt][r] = __builtin_fmaf(c01, v, o[0][1][mt][r]);
+        o[1][0][mt][r] = __builtin_fmaf(c10, v, o[1][0][mt][r]);
+        o[1][1][mt][r] = __builtin_fmaf(c11, v, o[1][1][mt][r]);
+        acc[mt][r] = 0.f;
+      }
+    kc = 0;
+    comp++;
+  };
+  // steps are numbered 0 .. nit-1 (nit is even); step s is staged through register set s & 1 and
+  // LDS buffer s & 1.  Entering iteration `it`: LDS holds step it, set (it+1)&1 holds / is
+  // receiving step it+1, and step it+2 is issued into the other set as soon as that set was stored.
+  const int nit = 16 * nk;
+  gload(0);
+  sstore(0, 0);
+  gload(1);
+  gload(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int it = 0; it < nit; it += 2) {
+    compute(0);
+    sstore(1, 1);                       // step it+1 (its loads were issued two steps ago)
+    if (it + 3 < nit) gload(1);         // step it+3
+    __syncthreads();
+    if (++kc == nk) flush();
+    compute(1);
+    if (it + 2 < nit) sstore(0, 0);     // step it+2
+    if (it + 4 < nit) gload(0);         // step it+4
+    __syncthreads();
+    if (++kc == nk) flush();
+  }
+
+  // epilogue: bias + activation + width mask, NHWC (or the max over the tile when pooling)
+  const int th = p.H >> 1, tw = (p.W + 1) >> 1;
+  const int n = n0 + wn * 32 + (lane & 31);
+  const float bias = p.bias[n];
+  const int act = p.act;
+  auto activate = [&](float v) {
+    const float neg = act == 2 ? 0.2f * v : (act == 1 ? 0.f : v);
+    return v > 0.f ? v : neg;
+  };
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int t = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (t >= p.ntile) continue;
+      const int q = t / tw, tx = t - q * tw;
+      const int b = q / th, ty = q - b * th;
+      const int wv = p.wvalid ? p.wvalid[b] : p.W;
+      float v[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const float e = activate(o[i][j][mt][r] + bias);
+          v[i][j] = (2 * tx + j < wv) ? e : 0.f;
+        }
+      if (p.pool) {
+        if (tx >= (p.W >> 1)) continue;   // odd W: the last column has no pool window
+        const float mx = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
+        p.y[(((long)b * th + ty) * (p.W >> 1) + tx) * p.N + n] = mx;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+            if (2 * tx + j < p.W) p.y[(((long)b * p.H + 2 * ty + i) * p.W + 2 * tx + j) * p.N + n] = v[i][j];
+      }
+    }
+}
+
+void launch_wino_gemm(const WinoGemm& p, hipStream_t s) {
+  const int nblk = ((p.ntile + WBM - 1) / WBM) * (p.N / WBN);
+  hipLaunchKernelGGL(wino_gemm_kernel, dim3(8 * ((nblk + 7) / 8)), dim3(256), 0, s, p);
+}
+
 static unsigned ew_blocks_w(long total) {
   long b = (total + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;

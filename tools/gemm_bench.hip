@@ -474,6 +474,9 @@ int main(int argc, char** argv) {
     RUN("bk32 nbuf2 (current)", 32, 2, 0, 2);
     RUN("bk32 nbuf1 minw3", 32, 1, 0, 3);
     RUNB("buffer loads nbuf1 minw3", 1, 3);
+    RUNB("  same, no stores", 1, 3, 1);
+    RUNB("  same, LDS-transposed stores", 1, 3, 2);
+    RUNB("  same, minw4", 1, 4);
     if (rep == 0) {
       unsigned long long* dst; CK(hipMalloc(&dst, (size_t)grid * 32));
       p.wvalid = (const int*)dst;

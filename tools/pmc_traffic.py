@@ -10,11 +10,14 @@ ORDER_DIRECT = ["normalize", "conv0_pool0", "conv1", "pool1", "conv2", "conv3", 
 ORDER_WINO = ["normalize", "conv0_pool0", "conv1", "pool1", "conv2", "conv3_win", "conv3", "conv3_wout", "pool2",
               "conv4_win", "conv4", "conv4_wout", "conv5_win", "conv5", "conv5_wout", "pool3",
               "conv6", "lstm0_ih", "lstm0_rec", "emb0", "lstm1_ih", "lstm1_rec", "classifier", "argmax", "ctc"]
-ORDER = ORDER_WINO if (len(sys.argv) > 4 and sys.argv[4] == "wino") else ORDER_DIRECT
+# fused: the GEMM applies the output transform itself (no *_wout launches)
+ORDER_FUSED = [k for k in ORDER_WINO if not k.endswith("_wout")]
+MODE = sys.argv[4] if len(sys.argv) > 4 else "direct"
+ORDER = {"wino": ORDER_WINO, "fused": ORDER_FUSED}.get(MODE, ORDER_DIRECT)
 
 
 def per_launch(d, counter):
-    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    f = (glob.glob(d + '/*counter_collection.csv') + glob.glob(d + '/*/*counter_collection.csv'))[0]
     rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and 'crnn::' in r['Kernel_Name']]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     vals = [float(r['Counter_Value']) for r in rows]
