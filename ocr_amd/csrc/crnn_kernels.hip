@@ -373,17 +373,23 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
     const float ra0 = ka < 3 ? 1.f : 0.f, ra1 = ka == 0 ? 0.f : (ka == 1 ? 1.f : -1.f);
     const float cb0 = kb < 3 ? 1.f : 0.f, cb1 = kb == 0 ? 0.f : (kb == 1 ? 1.f : -1.f);
     const float c00 = ra0 * cb0, c01 = ra0 * cb1, c10 = ra1 * cb0, c11 = ra1 * cb1;
+    // wave-uniform branches: 7 of the 16 components touch one output only, 4 touch all four
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const float c = i ? (j ? c11 : c10) : (j ? c01 : c00);
+        if (c != 0.f) {
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[i][j][mt][r] = __builtin_fmaf(c, acc[mt][r], o[i][j][mt][r]);
+        }
+      }
 #pragma unroll
     for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float v = acc[mt][r];
-        o[0][0][mt][r] = __builtin_fmaf(c00, v, o[0][0][mt][r]);
-        o[0][1][mt][r] = __builtin_fmaf(c01, v, o[0][1][mt][r]);
-        o[1][0][mt][r] = __builtin_fmaf(c10, v, o[1][0][mt][r]);
-        o[1][1][mt][r] = __builtin_fmaf(c11, v, o[1][1][mt][r]);
-        acc[mt][r] = 0.f;
-      }
+      for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
     kc = 0;
     comp++;
   };

@@ -11,7 +11,9 @@ ORDER_WINO = ["normalize", "conv0_pool0", "conv1", "pool1", "conv2", "conv3_win"
               "conv4_win", "conv4", "conv4_wout", "conv5_win", "conv5", "conv5_wout", "pool3",
               "conv6", "lstm0_ih", "lstm0_rec", "emb0", "lstm1_ih", "lstm1_rec", "classifier", "argmax", "ctc"]
 # fused: the GEMM applies the output transform itself (no *_wout launches)
-ORDER_FUSED = [k for k in ORDER_WINO if not k.endswith("_wout")]
+ORDER_FUSED = ["normalize", "conv0_pool0", "conv1_win", "conv1_pool1", "conv2_win", "conv2", "conv3_win", "conv3", "pool2",
+               "conv4_win", "conv4", "conv5_win", "conv5", "pool3",
+               "conv6", "lstm0_ih", "lstm0_rec", "emb0", "lstm1_ih", "lstm1_rec", "classifier", "argmax", "ctc"]
 MODE = sys.argv[4] if len(sys.argv) > 4 else "direct"
 ORDER = {"wino": ORDER_WINO, "fused": ORDER_FUSED}.get(MODE, ORDER_DIRECT)
 
