@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------
 constexpr int WBM = 128, WBN = 64, WBUF = (WBM + WBN) * LDT;
 
+template <int DBG>
 __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * WBUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -318,10 +319,13 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
 #pragma unroll
     for (int i = 0; i < 2; i++)
       rb[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, boff[i], l_k0 * 4, 0));
+    // past the last step the loader just re-reads component 15 (never stored to a buffer that is
+    // read): the loop body then has no branch around a load, so the compiler can wait for the older
+    // register set only (vmcnt(6)) instead of draining both
     l_k0 += BK;
     const bool wrap = l_k0 == p.Cin;
     l_k0 = wrap ? 0 : l_k0;
-    l_comp += wrap ? 1 : 0;
+    l_comp += (wrap && l_comp < 15) ? 1 : 0;
   };
   auto sstore = [&](int set, int buf) {
     float* sa = smem + buf * WBUF;
@@ -405,17 +409,24 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
 #pragma unroll 1
   for (int it = 0; it < nit; it += 2) {
     compute(0);
-    sstore(1, 1);                       // step it+1 (its loads were issued two steps ago)
-    if (it + 3 < nit) gload(1);         // step it+3
-    __syncthreads();
-    if (++kc == nk) flush();
+    if (DBG < 3) sstore(1, 1);      // step it+1 (its loads were issued two steps ago)
+    if (DBG != 2) gload(1);          // step it+3
+    if (DBG != 1 && DBG != 6) __syncthreads();
+    if (DBG != 4 && ++kc == nk) flush();
     compute(1);
-    if (it + 2 < nit) sstore(0, 0);     // step it+2
-    if (it + 4 < nit) gload(0);         // step it+4
-    __syncthreads();
-    if (++kc == nk) flush();
+    if (DBG < 3) sstore(0, 0);      // step it+2
+    if (DBG != 2) gload(0);          // step it+4
+    if (DBG != 1 && DBG != 6) __syncthreads();
+    if (DBG != 4 && ++kc == nk) flush();
   }
 
+  if (DBG == 5) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) asm volatile("" :: "v"(o[i][j][0]), "v"(o[i][j][1]));
+    return;
+  }
   // epilogue: bias + activation + width mask, NHWC (or the max over the tile when pooling)
   const int th = p.H >> 1, tw = (p.W + 1) >> 1;
   const int n = n0 + wn * 32 + (lane & 31);
@@ -425,40 +436,72 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
     const float neg = act == 2 ? 0.2f * v : (act == 1 ? 0.f : v);
     return v > 0.f ? v : neg;
   };
+  // tile -> (line, tile row, tile column): one reciprocal-multiply division per group of four
+  // consecutive tiles (exact for t < 2^24 with the +-1 fix-up), then carry increments
+  const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+  auto divmod = [](int t, int d, float inv, int& q, int& r) {
+    q = (int)((float)t * inv);
+    r = t - q * d;
+    if (r < 0) { q--; r += d; }
+    if (r >= d) { q++; r -= d; }
+  };
 #pragma unroll
   for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int t = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (t >= p.ntile) continue;
-      const int q = t / tw, tx = t - q * tw;
-      const int b = q / th, ty = q - b * th;
-      const int wv = p.wvalid ? p.wvalid[b] : p.W;
-      float v[2][2];
+    for (int rq = 0; rq < 4; rq++) {
+      const int t0 = m0 + wm * 64 + mt * 32 + 8 * rq + 4 * (lane >> 5);
+      int q, tx, b, ty;
+      divmod(t0, tw, inv_tw, q, tx);
+      divmod(q, th, inv_th, b, ty);
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int rr = 0; rr < 4; rr++) {
+        const int r = rq * 4 + rr;
+        if (t0 + rr < p.ntile) {
+          const int wv = p.wvalid ? p.wvalid[b] : p.W;
+          float v[2][2];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const float e = activate(o[i][j][mt][r] + bias);
-          v[i][j] = (2 * tx + j < wv) ? e : 0.f;
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+              const float e = activate(o[i][j][mt][r] + bias);
+              v[i][j] = (2 * tx + j < wv) ? e : 0.f;
+            }
+          if (p.pool) {
+            if (tx < (p.W >> 1)) {   // odd W: the last column has no pool window
+              const float mx = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
+              p.y[(((long)b * th + ty) * (p.W >> 1) + tx) * p.N + n] = mx;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+              for (int j = 0; j < 2; j++)
+                if (2 * tx + j < p.W) p.y[(((long)b * p.H + 2 * ty + i) * p.W + 2 * tx + j) * p.N + n] = v[i][j];
+          }
         }
-      if (p.pool) {
-        if (tx >= (p.W >> 1)) continue;   // odd W: the last column has no pool window
-        const float mx = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
-        p.y[(((long)b * th + ty) * (p.W >> 1) + tx) * p.N + n] = mx;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++)
-            if (2 * tx + j < p.W) p.y[(((long)b * p.H + 2 * ty + i) * p.W + 2 * tx + j) * p.N + n] = v[i][j];
+        // next tile in (line, row, column) order
+        tx++;
+        const bool cx = tx == tw;
+        tx = cx ? 0 : tx;
+        ty += cx ? 1 : 0;
+        const bool cy = ty == th;
+        ty = cy ? 0 : ty;
+        b += cy ? 1 : 0;
       }
     }
 }
 
 void launch_wino_gemm(const WinoGemm& p, hipStream_t s) {
   const int nblk = ((p.ntile + WBM - 1) / WBM) * (p.N / WBN);
-  hipLaunchKernelGGL(wino_gemm_kernel, dim3(8 * ((nblk + 7) / 8)), dim3(256), 0, s, p);
+  static int dbg = getenv("WDBG") ? atoi(getenv("WDBG")) : 0;
+  const dim3 g(8 * ((nblk + 7) / 8));
+  if (dbg == 1) hipLaunchKernelGGL(wino_gemm_kernel<1>, g, dim3(256), 0, s, p);
+  else if (dbg == 2) hipLaunchKernelGGL(wino_gemm_kernel<2>, g, dim3(256), 0, s, p);
+  else if (dbg == 3) hipLaunchKernelGGL(wino_gemm_kernel<3>, g, dim3(256), 0, s, p);
+  else if (dbg == 4) hipLaunchKernelGGL(wino_gemm_kernel<4>, g, dim3(256), 0, s, p);
+  else if (dbg == 5) hipLaunchKernelGGL(wino_gemm_kernel<5>, g, dim3(256), 0, s, p);
+  else if (dbg == 6) hipLaunchKernelGGL(wino_gemm_kernel<6>, g, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(wino_gemm_kernel<0>, g, dim3(256), 0, s, p);
 }
 
 static unsigned ew_blocks_w(long total) {
