@@ -278,7 +278,100 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------
 constexpr int WBM = 128, WBN = 64, WBUF = (WBM + WBN) * LDT;
 
-template <int DBG>
+// component (a,b) = comp complete: o[i][j] += AT[i][a] * AT[j][b] * acc (coefficients 0 / +-1, exact
+// as an fma; wave-uniform branches: 7 of the 16 components touch one output only, 4 touch all four)
+__device__ __forceinline__ void wino_flush(f32x16 (&acc)[2], f32x16 (&o)[2][2][2], int& kc, int& comp) {
+  const int ka = comp >> 2, kb = comp & 3;
+  const float ra0 = ka < 3 ? 1.f : 0.f, ra1 = ka == 0 ? 0.f : (ka == 1 ? 1.f : -1.f);
+  const float cb0 = kb < 3 ? 1.f : 0.f, cb1 = kb == 0 ? 0.f : (kb == 1 ? 1.f : -1.f);
+  const float c00 = ra0 * cb0, c01 = ra0 * cb1, c10 = ra1 * cb0, c11 = ra1 * cb1;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const float c = i ? (j ? c11 : c10) : (j ? c01 : c00);
+      if (c != 0.f) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[i][j][mt][r] = __builtin_fmaf(c, acc[mt][r], o[i][j][mt][r]);
+      }
+    }
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+  kc = 0;
+  comp++;
+}
+
+// bias + activation + width mask, NHWC (or the max over the tile when pooling)
+__device__ __forceinline__ void wino_epilogue(const f32x16 (&o)[2][2][2], const WinoGemm& p, int m0, int n0, int wm,
+                                              int wn, int lane) {
+  const int th = p.H >> 1, tw = (p.W + 1) >> 1;
+  const int n = n0 + wn * 32 + (lane & 31);
+  const float bias = p.bias[n];
+  const int act = p.act;
+  auto activate = [&](float v) {
+    const float neg = act == 2 ? 0.2f * v : (act == 1 ? 0.f : v);
+    return v > 0.f ? v : neg;
+  };
+  // tile -> (line, tile row, tile column): one reciprocal-multiply division per group of four
+  // consecutive tiles (exact for t < 2^24 with the +-1 fix-up), then carry increments
+  const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+  auto divmod = [](int t, int d, float inv, int& q, int& r) {
+    q = (int)((float)t * inv);
+    r = t - q * d;
+    if (r < 0) { q--; r += d; }
+    if (r >= d) { q++; r -= d; }
+  };
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      const int t0 = m0 + wm * 64 + mt * 32 + 8 * rq + 4 * (lane >> 5);
+      int q, tx, b, ty;
+      divmod(t0, tw, inv_tw, q, tx);
+      divmod(q, th, inv_th, b, ty);
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int r = rq * 4 + rr;
+        if (t0 + rr < p.ntile) {
+          const int wv = p.wvalid ? p.wvalid[b] : p.W;
+          float v[2][2];
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+              const float e = activate(o[i][j][mt][r] + bias);
+              v[i][j] = (2 * tx + j < wv) ? e : 0.f;
+            }
+          if (p.pool) {
+            if (tx < (p.W >> 1)) {   // odd W: the last column has no pool window
+              const float mx = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
+              p.y[(((long)b * th + ty) * (p.W >> 1) + tx) * p.N + n] = mx;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+              for (int j = 0; j < 2; j++)
+                if (2 * tx + j < p.W) p.y[(((long)b * p.H + 2 * ty + i) * p.W + 2 * tx + j) * p.N + n] = v[i][j];
+          }
+        }
+        // next tile in (line, row, column) order
+        tx++;
+        const bool cx = tx == tw;
+        tx = cx ? 0 : tx;
+        ty += cx ? 1 : 0;
+        const bool cy = ty == th;
+        ty = cy ? 0 : ty;
+        b += cy ? 1 : 0;
+      }
+    }
+}
+
+
 __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * WBUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -372,31 +465,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
   };
 
   int kc = 0, comp = 0;
-  auto flush = [&]() {   // component (a,b) complete: o[i][j] += AT[i][a] * AT[j][b] * acc
-    const int ka = comp >> 2, kb = comp & 3;
-    const float ra0 = ka < 3 ? 1.f : 0.f, ra1 = ka == 0 ? 0.f : (ka == 1 ? 1.f : -1.f);
-    const float cb0 = kb < 3 ? 1.f : 0.f, cb1 = kb == 0 ? 0.f : (kb == 1 ? 1.f : -1.f);
-    const float c00 = ra0 * cb0, c01 = ra0 * cb1, c10 = ra1 * cb0, c11 = ra1 * cb1;
-    // wave-uniform branches: 7 of the 16 components touch one output only, 4 touch all four
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const float c = i ? (j ? c11 : c10) : (j ? c01 : c00);
-        if (c != 0.f) {
-#pragma unroll
-          for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) o[i][j][mt][r] = __builtin_fmaf(c, acc[mt][r], o[i][j][mt][r]);
-        }
-      }
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
-    kc = 0;
-    comp++;
-  };
+  auto flush = [&]() { wino_flush(acc, o, kc, comp); };
   // steps are numbered 0 .. nit-1 (nit is even); step s is staged through register set s & 1 and
   // LDS buffer s & 1.  Entering iteration `it`: LDS holds step it, set (it+1)&1 holds / is
   // receiving step it+1, and step it+2 is issued into the other set as soon as that set was stored.
@@ -409,99 +478,181 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
 #pragma unroll 1
   for (int it = 0; it < nit; it += 2) {
     compute(0);
-    if (DBG < 3) sstore(1, 1);      // step it+1 (its loads were issued two steps ago)
-    if (DBG != 2) gload(1);          // step it+3
-    if (DBG != 1 && DBG != 6) __syncthreads();
-    if (DBG != 4 && ++kc == nk) flush();
+    sstore(1, 1);      // step it+1 (its loads were issued two steps ago)
+    gload(1);          // step it+3
+    __syncthreads();
+    if (++kc == nk) flush();
     compute(1);
-    if (DBG < 3) sstore(0, 0);      // step it+2
-    if (DBG != 2) gload(0);          // step it+4
-    if (DBG != 1 && DBG != 6) __syncthreads();
-    if (DBG != 4 && ++kc == nk) flush();
+    sstore(0, 0);      // step it+2
+    gload(0);          // step it+4
+    __syncthreads();
+    if (++kc == nk) flush();
   }
 
-  if (DBG == 5) {
+  wino_epilogue(o, p, m0, n0, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Same computation, operands staged with direct-to-LDS loads (buffer_load_dwordx4 ... lds): no
+// staging VGPRs and no ds_write; three unpadded 24 KB stages per block (two blocks per CU), loads
+// run two-plus steps ahead.  A wave-level load writes 1 KiB contiguously (lane l -> base + 16 l),
+// i.e. eight 128-byte rows back to back, so instead of padding rows the 16-byte k-chunks are
+// XOR-swizzled inside 256-byte row pairs: chunk position = ((row & 1) * 8 + kchunk) ^ ((row >> 1) & 15).
+// Each lane simply fetches the global chunk that belongs at its LDS position; the 16 lanes of a
+// fragment-read phase (16 consecutive rows, one k-chunk) then hit 16 distinct 16-byte bank groups.
+// The barrier that publishes step s+1 sits before the last k-group of step s, so its wait and
+// the first fragment reads of the next step run under 8 MFMAs.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int WSB = WBN * 32, WSA = WBM * 32;   // floats per B / A stage (unpadded)
+
+__global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(const WinoGemm p) {
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (WSA + WSB)];   // [B0 B1 B2 | A0 A1 A2], 72 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = p.N / WBN;
+  const int nblk = ((p.ntile + WBM - 1) / WBM) * ntn;
+  const int chunk = gridDim.x >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= nblk) return;
+  const int bm = L / ntn, bn = L - bm * ntn;
+  const int m0 = bm * WBM, n0 = bn * WBN;
+
+  // loader: LDS chunk position P = i * 256 + tid holds (row, kchunk) given by the swizzle
+  unsigned aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int P = i * 256 + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+    int m = m0 + 2 * S + (c16 >> 3);
+    m = m < p.ntile ? m : p.ntile - 1;
+    aoff[i] = (unsigned)(((long)m * p.Cin + (c16 & 7) * 4) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int P = i * 256 + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+    boff[i] = (unsigned)(((long)(n0 + 2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
+  }
+  const long bsA = (long)p.ntile * p.Cin, bsW = (long)p.N * p.Cin;
+  const int nk = p.Cin / BK;
+  int l_comp = 0, l_k0 = 0;   // position of the next K step to load (wave uniform)
+  // The loads are issued from inline asm: the compiler then keeps no vmcnt bookkeeping for them
+  // (it cannot tell the stages apart and would drain every load before each fragment read); the
+  // waits below are written by hand.
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;   // bytes, wave uniform
+  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  };
+  // running descriptor bases (bytes): advance by one component when the K position wraps
+  unsigned long long pa = (unsigned long long)p.V, pb = (unsigned long long)p.U;
+  const unsigned long long stepA = (unsigned long long)bsA * 4, stepB = (unsigned long long)bsW * 4;
+  auto gload = [&](int stage) {
+    const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+    const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+    const unsigned sa = lds0 + (3 * WSB + stage * WSA) * 4, sb = lds0 + stage * WSB * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) dma(a_rsrc, sa + i * 4096, aoff[i], l_k0 * 4);
+#pragma unroll
+    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * 4096, boff[i], l_k0 * 4);
+    // past the last step the loader re-reads component 15 into a stage nobody reads any more
+    l_k0 += BK;
+    const bool wrap = l_k0 == p.Cin;
+    l_k0 = wrap ? 0 : l_k0;
+    const bool adv = wrap && l_comp < 15;
+    l_comp += adv ? 1 : 0;
+    pa += adv ? stepA : 0;
+    pb += adv ? stepB : 0;
+  };
+
+  // fragment addresses (floats, inside a stage) per k-group; a1 = a0 + 32 rows = + 1024 floats
+  int aaddr[4], baddr[4];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int kg = 0; kg < 4; kg++) {
+      aaddr[kg] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (2 * kg + h)) ^ ((Ra >> 1) & 15)) << 2);
+      baddr[kg] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (2 * kg + h)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+
+  f32x16 acc[2], o[2][2][2];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    acc[0][r] = 0.f; acc[1][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++) asm volatile("" :: "v"(o[i][j][0]), "v"(o[i][j][1]));
-    return;
+      for (int j = 0; j < 2; j++) { o[i][j][0][r] = 0.f; o[i][j][1][r] = 0.f; }
   }
-  // epilogue: bias + activation + width mask, NHWC (or the max over the tile when pooling)
-  const int th = p.H >> 1, tw = (p.W + 1) >> 1;
-  const int n = n0 + wn * 32 + (lane & 31);
-  const float bias = p.bias[n];
-  const int act = p.act;
-  auto activate = [&](float v) {
-    const float neg = act == 2 ? 0.2f * v : (act == 1 ? 0.f : v);
-    return v > 0.f ? v : neg;
+  int kc = 0, comp = 0;
+  f32x4 a0[2], a1[2], b0[2];
+  auto frag = [&](int stage, int kg, int set) {
+    const float* sa = smem + 3 * WSB + stage * WSA;
+    const float* sb = smem + stage * WSB;
+    a0[set] = *(const f32x4*)(sa + aaddr[kg]);
+    a1[set] = *(const f32x4*)(sa + aaddr[kg] + 1024);
+    b0[set] = *(const f32x4*)(sb + baddr[kg]);
   };
-  // tile -> (line, tile row, tile column): one reciprocal-multiply division per group of four
-  // consecutive tiles (exact for t < 2^24 with the +-1 fix-up), then carry increments
-  const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
-  auto divmod = [](int t, int d, float inv, int& q, int& r) {
-    q = (int)((float)t * inv);
-    r = t - q * d;
-    if (r < 0) { q--; r += d; }
-    if (r >= d) { q++; r -= d; }
-  };
+  auto mfma8 = [&](int set) {
 #pragma unroll
-  for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-    for (int rq = 0; rq < 4; rq++) {
-      const int t0 = m0 + wm * 64 + mt * 32 + 8 * rq + 4 * (lane >> 5);
-      int q, tx, b, ty;
-      divmod(t0, tw, inv_tw, q, tx);
-      divmod(q, th, inv_th, b, ty);
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int r = rq * 4 + rr;
-        if (t0 + rr < p.ntile) {
-          const int wv = p.wvalid ? p.wvalid[b] : p.W;
-          float v[2][2];
-#pragma unroll
-          for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-              const float e = activate(o[i][j][mt][r] + bias);
-              v[i][j] = (2 * tx + j < wv) ? e : 0.f;
-            }
-          if (p.pool) {
-            if (tx < (p.W >> 1)) {   // odd W: the last column has no pool window
-              const float mx = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
-              p.y[(((long)b * th + ty) * (p.W >> 1) + tx) * p.N + n] = mx;
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-              for (int j = 0; j < 2; j++)
-                if (2 * tx + j < p.W) p.y[(((long)b * p.H + 2 * ty + i) * p.W + 2 * tx + j) * p.N + n] = v[i][j];
-          }
-        }
-        // next tile in (line, row, column) order
-        tx++;
-        const bool cx = tx == tw;
-        tx = cx ? 0 : tx;
-        ty += cx ? 1 : 0;
-        const bool cy = ty == th;
-        ty = cy ? 0 : ty;
-        b += cy ? 1 : 0;
-      }
+    for (int j = 0; j < 4; j++) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[set][j], b0[set][j], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[set][j], b0[set][j], acc[1], 0, 0, 0);
     }
+  };
+  // one K step on stage st; on entry fragment set 0 holds k-group 0 of this step
+  auto step = [&](auto ST) {
+    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
+    frag(st, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // publish the next step: its 6 loads were issued two steps ago (the 6 of the step after it may
+    // still be in flight); every wave has read all of stage st into registers by now
+    __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
+    __syncthreads();
+    gload(st);                            // step +3 reuses this stage
+    frag(nx, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kc == nk) wino_flush(acc, o, kc, comp);
+  };
+
+  const int nit = 16 * nk;
+  gload(0);
+  gload(1);
+  gload(2);
+  __builtin_amdgcn_s_waitcnt(0x0F7C);     // vmcnt(12): step 0 landed
+  __syncthreads();
+  frag(0, 0, 0);
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): no LDS write may be in flight when the block ends
+  wino_epilogue(o, p, m0, n0, wm, wn, lane);
 }
 
 void launch_wino_gemm(const WinoGemm& p, hipStream_t s) {
   const int nblk = ((p.ntile + WBM - 1) / WBM) * (p.N / WBN);
-  static int dbg = getenv("WDBG") ? atoi(getenv("WDBG")) : 0;
+  static const bool dma = !(getenv("CRNN_WINO_DMA") && atoi(getenv("CRNN_WINO_DMA")) == 0);
   const dim3 g(8 * ((nblk + 7) / 8));
-  if (dbg == 1) hipLaunchKernelGGL(wino_gemm_kernel<1>, g, dim3(256), 0, s, p);
-  else if (dbg == 2) hipLaunchKernelGGL(wino_gemm_kernel<2>, g, dim3(256), 0, s, p);
-  else if (dbg == 3) hipLaunchKernelGGL(wino_gemm_kernel<3>, g, dim3(256), 0, s, p);
-  else if (dbg == 4) hipLaunchKernelGGL(wino_gemm_kernel<4>, g, dim3(256), 0, s, p);
-  else if (dbg == 5) hipLaunchKernelGGL(wino_gemm_kernel<5>, g, dim3(256), 0, s, p);
-  else if (dbg == 6) hipLaunchKernelGGL(wino_gemm_kernel<6>, g, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(wino_gemm_kernel<0>, g, dim3(256), 0, s, p);
+  if (dma) hipLaunchKernelGGL(wino_gemm_dma_kernel, g, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(wino_gemm_kernel, g, dim3(256), 0, s, p);
 }
 
 static unsigned ew_blocks_w(long total) {

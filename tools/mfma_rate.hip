@@ -95,9 +95,49 @@ template <int NACC> void run(int wps, float* d) {
   const double fl = 256.0 * wps * 4 * iters * 16 * 4096.0;
   printf("nacc %d waves/SIMD %d: %.3f ms  %.1f TF/s\n", NACC, wps, ms, fl / ms / 1e9);
 }
+// core clock during an MFMA kernel: s_memtime (shader clock) against s_memrealtime (100 MHz)
+__global__ __launch_bounds__(256) void kclk(unsigned long long* st, int iters) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; i++) for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  float x = 1.f + threadIdx.x, y = 2.f;
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; it++)
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[i], 0, 0, 0);
+  float s = 0;
+  for (int i = 0; i < 4; i++) for (int r = 0; r < 16; r++) s += acc[i][r];
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { st[blockIdx.x * 2] = c1 - c0; st[blockIdx.x * 2 + 1] = r1 - r0; }
+  if (s == 12345.f) st[0] = 0;
+}
+__global__ __launch_bounds__(256) void kstream(const float4* a, float4* b, size_t n, int reps) {
+  for (int r = 0; r < reps; r++)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+      float4 v = a[i]; v.x += 1.f; b[i] = v;
+    }
+}
+void clocks() {
+  unsigned long long* st; hipMalloc(&st, 1024 * 16);
+  float4 *a, *b; const size_t n = 64u << 20; hipMalloc(&a, n * 16); hipMalloc(&b, n * 16);   // 2 x 1 GiB
+  hipMemset(a, 0, n * 16);
+  hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+  for (int mode = 0; mode < 2; mode++) {
+    hipDeviceSynchronize();
+    if (mode) kstream<<<2048, 256, 0, s2>>>(a, b, n, 8);
+    kclk<<<1024, 256, 0, s1>>>(st, 4000);
+    hipDeviceSynchronize();
+    unsigned long long h[2048]; hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost);
+    double f = 0; for (int i = 0; i < 1024; i++) f += (double)h[2 * i] / (double)h[2 * i + 1];
+    printf("MFMA kernel %s: core clock %.0f MHz (s_memtime / s_memrealtime x 100 MHz)\n",
+           mode ? "with an HBM streaming kernel beside it" : "alone", f / 1024 * 100);
+  }
+}
 int main() {
   float* d; hipMalloc(&d, 4);
   for (int wps = 1; wps <= 4; wps *= 2) { run<1>(wps, d); run<2>(wps, d); run<4>(wps, d); }
+  clocks();
   run2<0>(d); run2<1>(d); run2<2>(d); run2<3>(d); run2<4>(d); run2<5>(d); run2<6>(d);
   return 0;
 }
