@@ -53,3 +53,20 @@ def test_python_class_mirrors_reference_signature():
     for name in ("load_weights", "ocr", "predict", "predict_job", "predict_batch"):
         assert callable(getattr(CRNN, name))
     assert list(inspect.signature(CRNN.predict_batch).parameters) == ["self", "boxes", "batch_size"]
+
+
+def test_load_weights_pth_host_side(tmp_path, synth_en):
+    """The .pth reader and the weight repack are host code: they run without a GPU (the device is
+    only touched on the first compute call)."""
+    import numpy as np
+    import torch
+    from ocr_amd.crnn import keys
+    from ocr_amd.crnn.network_hip import CRNN
+    path = str(tmp_path / "w.pth")
+    torch.save({"module." + k: torch.from_numpy(np.asarray(v)) for k, v in synth_en.items()}, path)
+    m = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish)
+    m.load_weights(path)
+    bad = dict(synth_en)
+    bad.pop("cnn.conv3.weight")
+    with pytest.raises(Exception):
+        CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish).load_state_dict(bad)

@@ -200,3 +200,20 @@ def test_ocr_context_adapter(golden, hip_zh):
     assert ctx.batch_ocr(images) == want
     assert ctx.batch_ocr([]) == []
     assert ctx.ocr(crops[0]) == want[0] and ctx.ocr(None) == "" and ctx._chinese_ocr_instance(crops[1]) == want[1]
+
+
+@pytest.mark.gpu
+def test_load_weights_pth_with_module_prefix(tmp_path, golden, synth_en):
+    """network_torch.py:110-120: a flat .pth whose keys carry the DataParallel 'module.' prefix."""
+    import torch
+    from ocr_amd.crnn import keys
+    from ocr_amd.crnn.network_hip import CRNN
+    path = str(tmp_path / "ocr-english.pth")
+    torch.save({"module." + k: torch.from_numpy(np.asarray(v)) for k, v in synth_en.items()}, path)
+    a = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish, device=0)
+    a.load_weights(path)
+    b = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish, device=0)
+    b.load_state_dict(synth_en)
+    G, M = golden
+    lines = [G["var/%d/gray" % w] for w in M["var_widths"]]
+    assert a.predict_lines(lines) == b.predict_lines(lines) == M["var_en"]
