@@ -108,6 +108,21 @@ CRNN_API int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, cons
                        int32_t n, int32_t pad_mode, int32_t tmax, int32_t* out_raw, int32_t* out_lab,
                        int32_t* out_len, int32_t* out_t, float* out_logits);
 
+/* Crops that are rectangles of ONE page.  The detectors slice every crop out of the
+ * page they were given -- im0[y1:y2, x1:x2] at obj_det/vat_detect.py:291,318, stock_detect_v2.py:134,
+ * stock_detect.py:128, bill_detect.py:115 -- and TextOcrModel hands the slices to ocr_predict one by
+ * one (ocr_context.py:119,307).  crnn_set_page uploads the page once (HxWx3 BGR or HxW gray uint8,
+ * rows row_stride bytes apart) and keeps it in device memory until the next crnn_set_page;
+ * crnn_predict_rects then runs crnn_predict_batch's path on n rectangles rects[n][4] =
+ * (x1, y1, x2, y2), x2/y2 exclusive and clipped to the page like a numpy slice, with the gray
+ * conversion and resize reading straight from the resident page.  Outputs, pad_mode and error codes
+ * as crnn_predict_batch (CRNN_ERR_ZERO_H for an empty rectangle, CRNN_ERR_STATE without a page). */
+CRNN_API int crnn_set_page(crnn_handle* h, const uint8_t* page, int32_t height, int32_t width,
+                  int32_t row_stride, int32_t channels);
+CRNN_API int crnn_predict_rects(crnn_handle* h, const int32_t* rects, int32_t n, int32_t pad_mode,
+                       int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t,
+                       float* out_logits);
+
 /* The same path for lines already resident in device memory at height 32 (the layout the
  * width-bucketing scheduler and bench.py use): d_gray uint8 [n,32,w] device pointer; widths
  * host int32[n] (valid width of each line, <= w) or NULL when every line is w wide.

@@ -7,15 +7,19 @@ the only gather is of decoded strings on the host.
 """
 
 
-def width_buckets(widths, max_batch=256, width_spread=1.25):
+def width_buckets(widths, max_batch=256, width_spread=1.25, min_cols=0):
     """Indices of `widths` grouped into buckets of <= max_batch lines whose widest line is at most
     width_spread x the narrowest.  Lines narrower than 8 (decoded as '' by predict) ride along in
-    the first bucket: the library skips them."""
+    the first bucket: the library skips them.
+    min_cols: a bucket is not cut for its width spread while it holds fewer than min_cols padded
+    columns (lines x widest line).  A small batch is latency-bound on the device (the recurrence takes
+    T sequential steps whatever the batch), so for a page's worth of crops one padded batch beats
+    several exact ones; the per-line width masks keep the results identical either way."""
     order = sorted(range(len(widths)), key=lambda i: (widths[i], i))
     buckets, cur, lo = [], [], None
     for i in order:
         w = max(widths[i], 8)
-        if cur and (len(cur) >= max_batch or w > lo * width_spread):
+        if cur and (len(cur) >= max_batch or (w > lo * width_spread and len(cur) * w >= min_cols)):
             buckets.append(cur)
             cur, lo = [], None
         if lo is None:

@@ -52,6 +52,7 @@ class CRNN(object):
             device = int(os.environ.get("CRNN_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         self.device = device
         self._lib = _capi.lib()
+        self._page_shape = None
         cfg = _capi.Config(imgH, nc, nclass, nh, int(bool(leakyRelu)), int(bool(lstmFlag)), device, lanes,
                            {'fp32': _capi.FP32, 'bf16': _capi.BF16}[precision], 0)
         h = C.c_void_p()
@@ -162,12 +163,13 @@ class CRNN(object):
         return boxes
 
     # ------------------------------------------------ batched, predict-exact API
-    def predict_lines(self, images, max_batch=256, width_spread=1.25):
+    def predict_lines(self, images, max_batch=256, width_spread=1.25, min_cols=24576):
         """Texts of many lines, each identical to ``predict`` on that line alone.
 
         Lines are sorted by resized width and cut into buckets (at most ``max_batch`` lines, widest
-        / narrowest <= ``width_spread``); each bucket is one padded device batch with per-line width
-        masks.  ``images``: PIL 'L' images, uint8 HxW arrays or HxWx3 BGR arrays."""
+        / narrowest <= ``width_spread``, not enforced while a bucket has fewer than ``min_cols`` padded
+        columns -- small batches are latency-bound); each bucket is one padded device batch with per-line
+        width masks.  ``images``: PIL 'L' images, uint8 HxW arrays or HxWx3 BGR arrays."""
         arrs = []
         for im in images:
             a = np.asarray(im) if not (hasattr(im, "mode") and hasattr(im, "size")) else _as_gray_array(im)
@@ -195,11 +197,70 @@ class CRNN(object):
                 for i, t in zip(bucket, self._texts(lab, ln)):
                     out[keep[i]] = t
             return out
-        for bucket in width_buckets(widths, max_batch, width_spread):
+        for bucket in width_buckets(widths, max_batch, width_spread, min_cols):
             lab, ln, _, _, _ = self._run([arrs[i] for i in bucket], pad_mode)
             for i, t in zip(bucket, self._texts(lab, ln)):
                 out[i] = t
         return out
+
+    # ------------------------------------------- crops as rectangles of one page
+    def set_page(self, page):
+        """Upload a page (HxWx3 uint8 BGR as cv2.imread gives it, or HxW gray; any row stride) once;
+        it stays in device memory until the next set_page."""
+        a = np.asarray(page)
+        if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3) or a.size == 0:
+            raise ValueError("set_page expects a non-empty HxW or HxWx3 uint8 array, got %s %s" % (a.dtype, a.shape))
+        ch = 1 if a.ndim == 2 else 3
+        if a.strides[-1] != 1 or (a.ndim == 3 and a.strides[1] != 3) or a.strides[0] < a.shape[1] * ch:
+            a = np.ascontiguousarray(a)
+        self._page_shape = a.shape[:2]
+        _capi.check(self._h, self._lib.crnn_set_page(self._h, a.ctypes.data, a.shape[0], a.shape[1], a.strides[0], ch))
+
+    def predict_rects(self, rects, max_batch=256, width_spread=1.25, min_cols=24576):
+        """Texts of the crops page[y1:y2, x1:x2] for rects = [(x1, y1, x2, y2), ...] of the page given to
+        set_page -- what ``[self.ocr(page[y1:y2, x1:x2]) for ...]`` returns (ocr_context.py:119,307 fed by
+        vat_detect.py:318), without cutting or uploading the crops: the resize reads the resident page.
+        Width-bucketed like predict_lines; ends beyond the page are clipped as numpy slicing does."""
+        r = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4)
+        n = len(r)
+        if n == 0:
+            return []
+        if (r < 0).any():
+            raise ValueError("negative rectangle coordinate")
+        if self._page_shape is None:
+            raise RuntimeError("no page: call set_page first")
+        ph, pw = self._page_shape
+        hh = np.minimum(r[:, 3], ph) - r[:, 1]
+        ww = np.minimum(r[:, 2], pw) - r[:, 0]
+        if (hh <= 0).any():
+            raise ZeroDivisionError("float division by zero")       # util.py:8 on an empty crop
+        widths = [_capi.check(self._h, self._lib.crnn_resized_width(self._h, int(max(w, 0)), int(h)))
+                  for w, h in zip(ww, hh)]
+        if min(widths) <= 0:
+            raise ValueError("height and width must be > 0")
+        from .batching import width_buckets
+        out = [None] * n
+        exact = 1.0 if self.leakyRelu else width_spread
+        for bucket in width_buckets(widths, max_batch, exact, 0 if self.leakyRelu else min_cols):
+            if self.leakyRelu and widths[bucket[0]] < 8:
+                for i in bucket:
+                    out[i] = ''
+                continue
+            rb = np.ascontiguousarray(r[bucket])
+            tmax = max(1, self._lib.crnn_out_len(max(widths[i] for i in bucket)))
+            lab = np.zeros((len(bucket), tmax), np.int32)
+            ln = np.zeros(len(bucket), np.int32)
+            mode = _capi.PAD_REFERENCE if self.leakyRelu else _capi.PAD_PER_LINE
+            _capi.check(self._h, self._lib.crnn_predict_rects(self._h, rb.ctypes.data, len(bucket), mode, tmax, None,
+                                                              lab.ctypes.data, ln.ctypes.data, None, None))
+            for i, t in zip(bucket, self._texts(lab, ln)):
+                out[i] = t
+        return out
+
+    def ocr_page(self, page, rects):
+        """set_page + predict_rects."""
+        self.set_page(page)
+        return self.predict_rects(rects)
 
     # ------------------------------------------------------------- debug / test
     def forward_logits(self, images, pad_mode=_capi.PAD_PER_LINE):

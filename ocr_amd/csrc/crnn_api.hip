@@ -51,6 +51,7 @@ struct Lane {
   DevBuf arena;      // activations
   DevBuf pre;        // preprocessing scratch (sources, temp, coefficients, jobs)
   DevBuf io;         // per-call small buffers (outputs of the host path)
+  DevBuf stage;      // PINNED HOST memory: packed sources on their way to the device
   float* st[11] = {};          // where the stages of the last run live (crnn_debug_stage)
   size_t st_floats[11] = {};
 };
@@ -70,6 +71,9 @@ struct crnn_handle {
   // Winograd F(2x2,3x3) weights U[16][Cout][Cin] for the layers in wino_mask (fp32 path only)
   std::vector<float> h_wino[7];
   unsigned wino_mask = 0;
+  // resident page for crnn_set_page / crnn_predict_rects (crops are rectangles of one page)
+  DevBuf page;
+  int page_h = 0, page_w = 0, page_ch = 0;
   bool wino_fused = true;   // GEMM + output transform in one kernel (CRNN_WINO_FUSED=0: separate kernels)
   // bf16 copies (precision == CRNN_BF16): conv1..6, W_ih, embeddings / linear, packed W_hh
   std::vector<uint16_t> hb_conv_w[7], hb_wih[2], hb_whhp[2], hb_emb_w[2], hb_lin_w;
@@ -134,6 +138,21 @@ int ensure_buf(crnn_handle* h, DevBuf& b, size_t bytes) {
   return 0;
 }
 
+// pinned host staging (page and crop uploads): pageable hipMemcpy2D ran at 0.5 GB/s for an 11.6 MB page
+int ensure_host(crnn_handle* h, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return 0;
+  if (b.p) {
+    HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+    HIPCHK(h, hipHostFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 4096;
+  HIPCHK(h, hipHostMalloc(&b.p, want, hipHostMallocDefault));
+  b.cap = want;
+  return 0;
+}
+
 int upload(crnn_handle* h, const std::vector<float>& src, float** dst) {
   if (src.empty()) { *dst = nullptr; return 0; }
   HIPCHK(h, hipMalloc((void**)dst, src.size() * sizeof(float)));
@@ -161,8 +180,9 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     for (Lane& L : h->lanes) {
       L.ev_valid = false;
       L.nk = 0;
-      L.arena = DevBuf(); L.pre = DevBuf(); L.io = DevBuf();
+      L.arena = DevBuf(); L.pre = DevBuf(); L.io = DevBuf(); L.stage = DevBuf();
     }
+    h->page = DevBuf(); h->page_h = h->page_w = h->page_ch = 0;
   }
   if (!h->dev_ready) {
     int ndev = 0;
@@ -517,9 +537,12 @@ int prepare_plan(crnn_handle* h, const Geo& g, Plan& p) {
 // Gray conversion + Pillow-exact resize + normalise for a set of host images,
 // into d_x [nb,32,Wp].  sel lists the image indices to process, dw their
 // resized widths.
+// With rect_off != nullptr the sources are rectangles of the page already in HBM (h->page): rect_off[i]
+// is the byte offset of rectangle i's first pixel, rows are page rows, nothing is uploaded but the
+// coefficient tables.
 int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
                    const int32_t* row_strides, const int32_t* channels, const std::vector<int>& sel,
-                   const std::vector<int>& dw, int Wp, float* d_x) {
+                   const std::vector<int>& dw, int Wp, float* d_x, const int64_t* rect_off = nullptr) {
   const int nb = (int)sel.size();
   std::vector<ResizeJob> jobs(nb);
   std::vector<int32_t> coef;
@@ -531,9 +554,14 @@ int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* he
     ResizeJob& J = jobs[j];
     const int sh = heights[i], sw = widths[i], ch = channels[i];
     J.sh = sh; J.sw = sw; J.ch = ch; J.dw = dw[j];
-    J.stride = sw * ch;  // repacked tightly on upload
-    J.src_off = (int64_t)src_bytes;
-    src_bytes += ((size_t)sh * J.stride + 15) / 16 * 16;
+    if (rect_off) {
+      J.stride = h->page_w * h->page_ch;
+      J.src_off = rect_off[i];
+    } else {
+      J.stride = sw * ch;  // repacked tightly on upload
+      J.src_off = (int64_t)src_bytes;
+      src_bytes += ((size_t)sh * J.stride + 15) / 16 * 16;
+    }
     J.ksh = resample_coeffs(sw, J.dw, bh, kh);
     J.ksv = resample_coeffs(sh, 32, bv, kv);
     J.ybox_first = bv[0];
@@ -551,23 +579,26 @@ int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* he
     if (J.dw > max_dw) max_dw = J.dw;
   }
   // pack the sources (rows may be strided views of a page: ocr_context.py:307, vat_detect.py:318)
-  std::vector<uint8_t> src(src_bytes);
-  for (int j = 0; j < nb; j++) {
+  int rc = ensure_host(h, h->cur->stage, src_bytes + 16);
+  if (rc) return rc;
+  uint8_t* src = (uint8_t*)h->cur->stage.p;
+  for (int j = 0; j < nb && !rect_off; j++) {
     const int i = sel[j];
     const size_t rowb = (size_t)widths[i] * channels[i];
     for (int y = 0; y < heights[i]; y++)
-      memcpy(src.data() + jobs[j].src_off + y * rowb, imgs[i] + (size_t)y * row_strides[i], rowb);
+      memcpy(src + jobs[j].src_off + y * rowb, imgs[i] + (size_t)y * row_strides[i], rowb);
   }
   const size_t a = (src_bytes + 255) / 256 * 256, b = (tmp_bytes + 255) / 256 * 256;
   const size_t c = (coef.size() * 4 + 255) / 256 * 256, d = (jobs.size() * sizeof(ResizeJob) + 255) / 256 * 256;
-  int rc = ensure_buf(h, h->cur->pre, a + b + c + d);
+  rc = ensure_buf(h, h->cur->pre, a + b + c + d);
   if (rc) return rc;
   uint8_t* d_src = (uint8_t*)h->cur->pre.p;
   uint8_t* d_tmp = d_src + a;
+  if (rect_off) d_src = (uint8_t*)h->page.p;
   int32_t* d_coef = (int32_t*)(d_tmp + b);
   ResizeJob* d_jobs = (ResizeJob*)((char*)d_coef + c);
   hipStream_t s = h->cur->stream;
-  HIPCHK(h, hipMemcpyAsync(d_src, src.data(), src_bytes, hipMemcpyHostToDevice, s));
+  if (!rect_off && src_bytes) HIPCHK(h, hipMemcpyAsync(d_src, src, src_bytes, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(d_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(ResizeJob), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipEventRecord(h->cur->ev[0], s));
@@ -794,17 +825,12 @@ int crnn_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* h
   return 0;
 }
 
-int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
-                       const int32_t* row_strides, const int32_t* channels, int32_t n, int32_t pad_mode,
-                       int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t,
-                       float* out_logits) {
-  if (!h) return CRNN_ERR_ARG;
-  std::lock_guard<std::mutex> lk(h->mu);
-  h->cur = &h->lanes[0];
-  if (n <= 0 || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
-  if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
-  int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
-  if (rc) return rc;
+// crnn_predict_batch / crnn_predict_rects after argument checks (lock held, h->cur set)
+static int predict_core(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
+                        const int32_t* row_strides, const int32_t* channels, const int64_t* rect_off, int32_t n,
+                        int32_t pad_mode, int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len,
+                        int32_t* out_t, float* out_logits) {
+  int rc;
   std::vector<int> sel, dw;
   int Wp = 0;
   for (int i = 0; i < n; i++) {
@@ -827,7 +853,7 @@ int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t
   if ((rc = ensure_buf(h, h->cur->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
   int32_t* d_lab = (int32_t*)h->cur->io.p;
   int32_t* d_len = d_lab + ((nT + 63) / 64) * 64;
-  if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, Wp, p.x))) return rc;
+  if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, Wp, p.x, rect_off))) return rc;
   std::vector<int32_t> wv(dw.begin(), dw.end());
   const bool uniform = pad_mode == CRNN_PAD_REFERENCE;
   if ((rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len, out_logits != nullptr))) return rc;
@@ -853,6 +879,73 @@ int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t
              sizeof(float) * (size_t)Ti * h->cfg.nclass);
   }
   return 0;
+}
+
+int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
+                       const int32_t* row_strides, const int32_t* channels, int32_t n, int32_t pad_mode,
+                       int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t,
+                       float* out_logits) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->cur = &h->lanes[0];
+  if (n <= 0 || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
+  if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
+  int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
+  if (rc) return rc;
+  return predict_core(h, imgs, heights, widths, row_strides, channels, nullptr, n, pad_mode, tmax, out_raw, out_lab,
+                      out_len, out_t, out_logits);
+}
+
+int crnn_set_page(crnn_handle* h, const uint8_t* page, int32_t height, int32_t width, int32_t row_stride,
+                  int32_t channels) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->cur = &h->lanes[0];
+  if (!page || height <= 0 || width <= 0) return fail(h, CRNN_ERR_ARG, "empty page");
+  if (channels != 1 && channels != 3) return fail(h, CRNN_ERR_ARG, "channels must be 1 (gray) or 3 (BGR)");
+  if (row_stride < width * channels) return fail(h, CRNN_ERR_ARG, "row stride smaller than a row");
+  int rc = ensure_device(h, false);
+  if (rc) return rc;
+  const size_t rowb = (size_t)width * channels, bytes = rowb * height;
+  // any lane may still be reading the previous page
+  for (int i = 0; i < h->nlanes; i++) HIPCHK(h, hipStreamSynchronize(h->lanes[i].stream));
+  if ((rc = ensure_buf(h, h->page, bytes + 256))) return rc;
+  if ((rc = ensure_host(h, h->cur->stage, bytes))) return rc;
+  uint8_t* st = (uint8_t*)h->cur->stage.p;
+  if ((size_t)row_stride == rowb) memcpy(st, page, bytes);
+  else for (int y = 0; y < height; y++) memcpy(st + (size_t)y * rowb, page + (size_t)y * row_stride, rowb);
+  HIPCHK(h, hipMemcpyAsync(h->page.p, st, bytes, hipMemcpyHostToDevice, h->cur->stream));
+  HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+  h->page_h = height; h->page_w = width; h->page_ch = channels;
+  return 0;
+}
+
+int crnn_predict_rects(crnn_handle* h, const int32_t* rects, int32_t n, int32_t pad_mode, int32_t tmax,
+                       int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t, float* out_logits) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->cur = &h->lanes[0];
+  if (n <= 0 || !rects || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
+  if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
+  if (!h->page.p || h->page_h <= 0) return fail(h, CRNN_ERR_STATE, "no page: call crnn_set_page first");
+  // im0[y1:y2, x1:x2] (vat_detect.py:318): ends are clipped to the page like a numpy slice; negative
+  // coordinates (which numpy would wrap) are refused
+  std::vector<int32_t> hh(n), ww(n), st(n), cc(n);
+  std::vector<int64_t> off(n);
+  for (int i = 0; i < n; i++) {
+    const int x1 = rects[4 * i], y1 = rects[4 * i + 1];
+    const int x2 = std::min(rects[4 * i + 2], h->page_w), y2 = std::min(rects[4 * i + 3], h->page_h);
+    if (x1 < 0 || y1 < 0 || rects[4 * i + 2] < 0 || rects[4 * i + 3] < 0)
+      return fail(h, CRNN_ERR_ARG, "negative rectangle coordinate");
+    hh[i] = std::max(0, y2 - y1); ww[i] = std::max(0, x2 - x1);
+    st[i] = h->page_w * h->page_ch; cc[i] = h->page_ch;
+    off[i] = ((int64_t)y1 * h->page_w + x1) * h->page_ch;
+    if (hh[i] == 0) return fail(h, CRNN_ERR_ZERO_H, "rectangle height 0 (ZeroDivisionError in resizeNormalize)");
+    if (resized_width(ww[i], hh[i], 32) <= 0)
+      return fail(h, CRNN_ERR_ZERO_W, "resized width 0 (height and width must be > 0)");
+  }
+  return predict_core(h, nullptr, hh.data(), ww.data(), st.data(), cc.data(), off.data(), n, pad_mode, tmax, out_raw,
+                      out_lab, out_len, out_t, out_logits);
 }
 
 int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_t w, const int32_t* widths,
@@ -990,11 +1083,12 @@ void crnn_destroy(crnn_handle* h) {
     }
     (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->db_lin_w); (void)hipFree(h->d_zero_bias);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino[i]);
+    (void)hipFree(h->page.p);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }
     for (int l = 0; l < h->nlanes; l++) {
       Lane& L = h->lanes[l];
-      (void)hipFree(L.arena.p); (void)hipFree(L.pre.p); (void)hipFree(L.io.p);
+      (void)hipFree(L.arena.p); (void)hipFree(L.pre.p); (void)hipFree(L.io.p); (void)hipHostFree(L.stage.p);
       for (int i = 0; i < 5; i++) (void)hipEventDestroy(L.ev[i]);
       for (int i = 0; i <= MAXK; i++) (void)hipEventDestroy(L.kev[i]);
       (void)hipStreamDestroy(L.stream);

@@ -53,3 +53,31 @@ class CrnnOcrContext(object):
             for i in good:
                 results[i] = self.ocr(images[i])
         return results
+
+    def page_ocr(self, page, boxes):
+        """Texts of the crops ``page[y1:y2, x1:x2]`` for boxes = [(x1, y1, x2, y2), ...]: what the
+        detectors do crop by crop (vat_detect.py:291,318 -> ocr_context.py:119) with ONE upload of the page;
+        the gray conversion and the resize read the rectangles from the page in device memory.
+        "" for a degenerate box, as the per-crop try/except of the reference gives."""
+        if page is None or len(boxes) == 0:
+            return [""] * len(boxes)
+        a = np.asarray(page)
+        results = [""] * len(boxes)
+        good = []
+        for i, b in enumerate(boxes):
+            x1, y1, x2, y2 = [int(v) for v in b]
+            if x1 < 0 or y1 < 0 or min(x2, a.shape[1]) - x1 <= 0 or min(y2, a.shape[0]) - y1 <= 0:
+                continue
+            good.append(i)
+        if not good:
+            return results
+        try:
+            self.crnn.set_page(a)
+            texts = self.crnn.predict_rects([boxes[i] for i in good], max_batch=self.max_batch)
+            for i, t in zip(good, texts):
+                results[i] = t
+        except Exception:
+            for i in good:
+                x1, y1, x2, y2 = [int(v) for v in boxes[i]]
+                results[i] = self.ocr(a[y1:y2, x1:x2])
+        return results

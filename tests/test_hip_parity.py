@@ -217,3 +217,38 @@ def test_load_weights_pth_with_module_prefix(tmp_path, golden, synth_en):
     G, M = golden
     lines = [G["var/%d/gray" % w] for w in M["var_widths"]]
     assert a.predict_lines(lines) == b.predict_lines(lines) == M["var_en"]
+
+
+@pytest.mark.gpu
+def test_page_rectangles_equal_cropped_lines(golden, hip_zh):
+    """crops given as rectangles of one resident page decode exactly as the same crops
+    cut on the host (CRNN.ocr on page[y1:y2, x1:x2], ocr_context.py:119 fed by vat_detect.py:318)."""
+    from ocr_amd.ocr_context import CrnnOcrContext
+    G, M = golden
+    rs = np.random.RandomState(7)
+    page = rs.randint(0, 256, size=(600, 900, 3)).astype(np.uint8)
+    # paste the invoice crops so that real text-like content is on the page
+    rects, y = [], 5
+    for k in sorted(k for k in G.files if k.startswith("inv/") and k.endswith("/bgr"))[:8]:
+        c = G[k]
+        h, w = c.shape[:2]
+        if y + h > page.shape[0] or w + 7 > page.shape[1]:
+            continue
+        page[y:y + h, 7:7 + w] = c
+        rects.append((7, y, 7 + w, y + h))
+        y += h + 3
+    rects += [(100, 300, 420, 333), (0, 0, 900, 40), (850, 550, 2000, 2000), (10, 500, 14, 540), (300, 100, 308, 140)]
+    want = [hip_zh.ocr(page[y1:y2, x1:x2]) for x1, y1, x2, y2 in rects]
+    assert hip_zh.ocr_page(page, rects) == want
+    # a strided view of a larger array as the page, gray pages, and the adapter's conventions
+    big = np.zeros((700, 1000, 3), np.uint8)
+    big[50:650, 60:960] = page
+    assert hip_zh.ocr_page(big[50:650, 60:960], rects) == want
+    gray = page[:, :, 1].copy()
+    hip_zh.set_page(gray)
+    assert hip_zh.predict_rects(rects[:4]) == hip_zh.predict_lines([gray[y1:y2, x1:x2] for x1, y1, x2, y2 in rects[:4]])
+    ctx = CrnnOcrContext(hip_zh)
+    got = ctx.page_ocr(page, rects + [(5, 5, 5, 30), (-3, 0, 10, 10)])
+    assert got[:len(rects)] == want and got[len(rects):] == ["", ""]
+    with pytest.raises(ZeroDivisionError):
+        hip_zh.predict_rects([(5, 5, 50, 5)])

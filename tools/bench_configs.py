@@ -70,6 +70,28 @@ def main():
                                   "note": "synthetic BGR crops with the 17 invoice crop sizes, host -> strings via "
                                           "predict_lines (H2D + gray + resize included); detectors absent, no pages/s"}
     assert len(texts) == ncrops
+
+    # ---------------- config 5, page form: one upload per page, crops as rectangles
+    npages, per_page = 24, 48
+    ph, pw = 2339, 1654                       # A4 at 200 dpi
+    pages, rects = [], []
+    for _ in range(npages):
+        pages.append(rs.randint(0, 256, size=(ph, pw, 3)).astype(np.uint8))
+        rr = []
+        for _ in range(per_page):
+            h, w, _c = shapes[rs.randint(len(shapes))]
+            x1, y1 = rs.randint(0, pw - w), rs.randint(0, ph - h)
+            rr.append((x1, y1, x1 + w, y1 + h))
+        rects.append(rr)
+    zh.ocr_page(pages[0], rects[0])
+    t0 = time.perf_counter()
+    nt = sum(len(zh.ocr_page(pg, rr)) for pg, rr in zip(pages, rects))
+    el = time.perf_counter() - t0
+    out["config5_page_rects"] = {"pages": npages, "crops_per_page": per_page, "pages_per_s": round(npages / el, 1),
+                                 "crops_per_s": round(nt / el, 1), "seconds": round(el, 3),
+                                 "note": "synthetic 1654x2339 BGR pages, 48 rectangles of the invoice crop sizes each; "
+                                         "page uploaded once (11.6 MB), gray+resize read the resident page; one "
+                                         "GPU, one lane, detectors absent"}
     print(json.dumps(out))
 
 
