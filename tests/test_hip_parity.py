@@ -252,3 +252,35 @@ def test_page_rectangles_equal_cropped_lines(golden, hip_zh):
     assert got[:len(rects)] == want and got[len(rects):] == ["", ""]
     with pytest.raises(ZeroDivisionError):
         hip_zh.predict_rects([(5, 5, 50, 5)])
+
+
+@pytest.mark.gpu
+def test_random_crops_against_oracle(hip_en, oracle_en):
+    """Seeded random crops (gray and BGR, heights 9..80, widths giving resized widths 8..~500) through the
+    whole path against the CPU oracle line by line: strings and raw arg-max identical, logits within
+    LOGIT_TOL.  Exercises odd widths at every layer (Winograd edge tiles, odd pooled widths, masks)."""
+    from oracle import oracle as orc
+    rs = np.random.RandomState(11)
+    crops = []
+    for k in range(24):
+        h = int(rs.randint(9, 81))
+        w = int(rs.randint(max(3, h // 4), h * 16))
+        shape = (h, w, 3) if k % 3 == 0 else (h, w)
+        a = rs.randint(0, 256, size=shape).astype(np.uint8)
+        # some structure: dark strokes on a light background
+        a[..., :] = np.where(rs.rand(*shape) < 0.8, 200 + a // 5, a // 3).astype(np.uint8)
+        crops.append(a)
+    got = hip_en.predict_lines(crops)
+    raw, tt, logits, _, _ = hip_en.forward_logits(crops)
+    from ocr_amd.crnn import keys
+    for i, a in enumerate(crops):
+        g = orc.bgr_to_gray(a) if a.ndim == 3 else a
+        x = orc.resize_normalize(g)
+        if x.shape[-1] < 8:
+            assert got[i] == ""
+            continue
+        full = oracle_en.forward(x[None])            # [T, 1, nclass]
+        idx, lg = orc.argmax(full)[0], full[:, 0, :]
+        assert got[i] == orc.decode(idx, keys.alphabetEnglish), i
+        assert tt[i] == len(idx) and np.array_equal(raw[i, :tt[i]], idx), i
+        assert np.abs(logits[i, :tt[i]] - lg).max() < LOGIT_TOL, i

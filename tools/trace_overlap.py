@@ -1,6 +1,6 @@
 """Analyse a rocprofv3 kernel trace of bench.py: per-kernel time per step under lane concurrency."""
 import csv, glob, collections, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*kernel_trace.csv') + glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'))[0]
 first, nsteps = int(sys.argv[2]), int(sys.argv[3])   # index of first timed conv0 launch, number of steps
 rows = list(csv.DictReader(open(f)))
 ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('crnn::', ''),
