@@ -504,32 +504,36 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
 // the first fragment reads of the next step run under 8 MFMAs.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-constexpr int WSB = WBN * 32, WSA = WBM * 32;   // floats per B / A stage (unpadded)
+constexpr int WSA = WBM * 32;   // floats per A stage (unpadded; the B stage is 32 floats x tile N)
 
-__global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(const WinoGemm p) {
-  __shared__ __attribute__((aligned(1024))) float smem[3 * (WSA + WSB)];   // [B0 B1 B2 | A0 A1 A2], 72 KB
+// NWN = waves along N: 2 -> 128 x 64 tile, 256 threads, two blocks per CU; 4 -> 128 x 128 tile, 512 threads,
+// one block per CU (a third fewer loads per MFMA, half the L2 -> LDS traffic).
+template <int NWN>
+__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino_gemm_dma_kernel(const WinoGemm p) {
+  constexpr int NT = 128 * NWN, TBN = 32 * NWN, SB = TBN * 32, NLA = 1024 / NT;   // threads, tile N, floats per B stage, A loads per thread
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (WSA + SB)];   // [B0 B1 B2 | A0 A1 A2], 72 / 96 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = p.N / WBN;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int ntn = p.N / TBN;
   const int nblk = ((p.ntile + WBM - 1) / WBM) * ntn;
   const int chunk = gridDim.x >> 3;
   const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (L >= nblk) return;
   const int bm = L / ntn, bn = L - bm * ntn;
-  const int m0 = bm * WBM, n0 = bn * WBN;
+  const int m0 = bm * WBM, n0 = bn * TBN;
 
   // loader: LDS chunk position P = i * 256 + tid holds (row, kchunk) given by the swizzle
-  unsigned aoff[4], boff[2];
+  unsigned aoff[NLA], boff[2];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int P = i * 256 + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+  for (int i = 0; i < NLA; i++) {
+    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
     int m = m0 + 2 * S + (c16 >> 3);
     m = m < p.ntile ? m : p.ntile - 1;
     aoff[i] = (unsigned)(((long)m * p.Cin + (c16 & 7) * 4) * 4);
   }
 #pragma unroll
   for (int i = 0; i < 2; i++) {
-    const int P = i * 256 + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
     boff[i] = (unsigned)(((long)(n0 + 2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
   }
   const long bsA = (long)p.ntile * p.Cin, bsW = (long)p.N * p.Cin;
@@ -549,11 +553,11 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(const WinoGemm p)
   auto gload = [&](int stage) {
     const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
     const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
-    const unsigned sa = lds0 + (3 * WSB + stage * WSA) * 4, sb = lds0 + stage * WSB * 4;
+    const unsigned sa = lds0 + (3 * SB + stage * WSA) * 4, sb = lds0 + stage * SB * 4;
 #pragma unroll
-    for (int i = 0; i < 4; i++) dma(a_rsrc, sa + i * 4096, aoff[i], l_k0 * 4);
+    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], l_k0 * 4);
 #pragma unroll
-    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * 4096, boff[i], l_k0 * 4);
+    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * NT * 16, boff[i], l_k0 * 4);
     // past the last step the loader re-reads component 15 into a stage nobody reads any more
     l_k0 += BK;
     const bool wrap = l_k0 == p.Cin;
@@ -587,8 +591,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(const WinoGemm p)
   int kc = 0, comp = 0;
   f32x4 a0[2], a1[2], b0[2];
   auto frag = [&](int stage, int kg, int set) {
-    const float* sa = smem + 3 * WSB + stage * WSA;
-    const float* sb = smem + stage * WSB;
+    const float* sa = smem + 3 * SB + stage * WSA;
+    const float* sb = smem + stage * SB;
     a0[set] = *(const f32x4*)(sa + aaddr[kg]);
     a1[set] = *(const f32x4*)(sa + aaddr[kg] + 1024);
     b0[set] = *(const f32x4*)(sb + baddr[kg]);
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(const WinoGemm p)
     __builtin_amdgcn_sched_barrier(0);
     // publish the next step: its 6 loads were issued two steps ago (the 6 of the step after it may
     // still be in flight); every wave has read all of stage st into registers by now
-    __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
+    __builtin_amdgcn_s_waitcnt(NWN == 2 ? 0x0076 : 0x0074);   // vmcnt(one step's loads: 6 / 4) lgkmcnt(0)
     __syncthreads();
     gload(st);                            // step +3 reuses this stage
     frag(nx, 0, 0);
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(const WinoGemm p)
   gload(0);
   gload(1);
   gload(2);
-  __builtin_amdgcn_s_waitcnt(0x0F7C);     // vmcnt(12): step 0 landed
+  __builtin_amdgcn_s_waitcnt(NWN == 2 ? 0x0F7C : 0x0F78);   // vmcnt(2 steps' loads): step 0 landed
   __syncthreads();
   frag(0, 0, 0);
   int it = 0;
@@ -649,9 +653,19 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_dma_kernel(const WinoGemm p)
 
 void launch_wino_gemm(const WinoGemm& p, hipStream_t s) {
   const int nblk = ((p.ntile + WBM - 1) / WBM) * (p.N / WBN);
-  static const bool dma = !(getenv("CRNN_WINO_DMA") && atoi(getenv("CRNN_WINO_DMA")) == 0);
+  // CRNN_WINO_DMA: 0 register-staged kernel, 1 128x64 tiles, 2 128x128 tiles, unset: per launch, whichever
+  // tile shape fills its block slots better (512 slots of 128x64 or 256 of 128x128; the wide tile is ~3 %
+  // faster when both fill their last round, and much slower when its last round is mostly empty)
+  static const int dma = getenv("CRNN_WINO_DMA") ? atoi(getenv("CRNN_WINO_DMA")) : -1;
   const dim3 g(8 * ((nblk + 7) / 8));
-  if (dma) hipLaunchKernelGGL(wino_gemm_dma_kernel, g, dim3(256), 0, s, p);
+  const int nb2 = ((p.ntile + WBM - 1) / WBM) * (p.N / 128);
+  bool wide = dma == 2;
+  if (dma < 0 && p.N % 128 == 0) {
+    const double e2 = (double)nblk / (((nblk + 511) / 512) * 512.0), e4 = (double)nb2 / (((nb2 + 255) / 256) * 256.0);
+    wide = e4 >= e2 && e4 >= 0.9;
+  }
+  if (wide && p.N % 128 == 0) hipLaunchKernelGGL(wino_gemm_dma_kernel<4>, dim3(8 * ((nb2 + 7) / 8)), dim3(512), 0, s, p);
+  else if (dma) hipLaunchKernelGGL(wino_gemm_dma_kernel<2>, g, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(wino_gemm_kernel, g, dim3(256), 0, s, p);
 }
 
