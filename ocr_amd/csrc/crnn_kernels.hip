@@ -168,49 +168,63 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
 // Winograd F(2x2,3x3) transforms (fp32, HBM-bound elementwise kernels; float4 over channels).
 // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  A^T = [1 1 1 0; 0 1 -1 -1].
 // ---------------------------------------------------------------------------
+// One thread owns a COLUMN of tiles (all tile rows of one line at one tile x, 4 channels): walking down,
+// each 4x4 input patch shares its top two rows with the previous tile's bottom two, so every input row
+// is loaded once per thread; horizontally adjacent threads read overlapping columns at the same time
+// (L1/L2 hits).  HBM reads drop from 2x the input (one thread per tile) to ~1x.
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V,
                                                       int B, int H, int W, int C) {
   const int th = H >> 1, tw = (W + 1) >> 1, C4 = C >> 2;
   const long ntile = (long)B * th * tw;
-  const long total = ntile * C4;
+  const long total = (long)B * tw * C4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
-    const long t = i / C4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th);
-    const int b = (int)(r / th);
+    const long r = i / C4;
+    const int tx = (int)(r % tw);
+    const int b = (int)(r / tw);
+    bool okx[4];
+    const float* px[4];
+#pragma unroll
+    for (int dx = 0; dx < 4; dx++) {
+      const int xx = 2 * tx - 1 + dx;
+      okx[dx] = (unsigned)xx < (unsigned)W;
+      px[dx] = x + ((long)b * H * W + (okx[dx] ? xx : 0)) * C + c4 * 4;
+    }
+    auto row = [&](int yy, f32x4 (&d)[4]) {
+      const bool oky = (unsigned)yy < (unsigned)H;
+#pragma unroll
+      for (int dx = 0; dx < 4; dx++) d[dx] = (oky && okx[dx]) ? *(const f32x4*)(px[dx] + (long)yy * W * C) : z;
+    };
     f32x4 d[4][4];
+    row(-1, d[0]);
+    row(0, d[1]);
+    for (int ty = 0; ty < th; ty++) {
+      row(2 * ty + 1, d[2]);
+      row(2 * ty + 2, d[3]);
+      const long t = ((long)b * th + ty) * tw + tx;
+      f32x4 u[4][4];   // B^T d (rows)
 #pragma unroll
-    for (int dy = 0; dy < 4; dy++) {
-      const int yy = 2 * ty - 1 + dy;
-#pragma unroll
-      for (int dx = 0; dx < 4; dx++) {
-        const int xx = 2 * tx - 1 + dx;
-        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        d[dy][dx] = ok ? *(const f32x4*)(x + (((long)b * H + yy) * W + xx) * C + c4 * 4) : z;
+      for (int j = 0; j < 4; j++) {
+        u[0][j] = d[0][j] - d[2][j];
+        u[1][j] = d[1][j] + d[2][j];
+        u[2][j] = d[2][j] - d[1][j];
+        u[3][j] = d[1][j] - d[3][j];
       }
-    }
-    f32x4 u[4][4];   // B^T d (rows)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      u[0][j] = d[0][j] - d[2][j];
-      u[1][j] = d[1][j] + d[2][j];
-      u[2][j] = d[2][j] - d[1][j];
-      u[3][j] = d[1][j] - d[3][j];
-    }
+      for (int k = 0; k < 4; k++) {   // (B^T d) B (columns)
+        const f32x4 v0 = u[k][0] - u[k][2];
+        const f32x4 v1 = u[k][1] + u[k][2];
+        const f32x4 v2 = u[k][2] - u[k][1];
+        const f32x4 v3 = u[k][1] - u[k][3];
+        float* o = V + ((long)(k * 4) * ntile + t) * C + c4 * 4;
+        *(f32x4*)(o) = v0;
+        *(f32x4*)(o + ntile * C) = v1;
+        *(f32x4*)(o + 2 * ntile * C) = v2;
+        *(f32x4*)(o + 3 * ntile * C) = v3;
+      }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {   // (B^T d) B (columns)
-      const f32x4 v0 = u[k][0] - u[k][2];
-      const f32x4 v1 = u[k][1] + u[k][2];
-      const f32x4 v2 = u[k][2] - u[k][1];
-      const f32x4 v3 = u[k][1] - u[k][3];
-      float* o = V + ((long)(k * 4) * ntile + t) * C + c4 * 4;
-      *(f32x4*)(o) = v0;
-      *(f32x4*)(o + ntile * C) = v1;
-      *(f32x4*)(o + 2 * ntile * C) = v2;
-      *(f32x4*)(o + 3 * ntile * C) = v3;
+      for (int j = 0; j < 4; j++) { d[0][j] = d[2][j]; d[1][j] = d[3][j]; }
     }
   }
 }
@@ -677,7 +691,7 @@ static unsigned ew_blocks_w(long total) {
 }
 
 void launch_wino_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s) {
-  const long total = (long)B * (H / 2) * ((W + 1) / 2) * (C / 4);
+  const long total = (long)B * ((W + 1) / 2) * (C / 4);
   hipLaunchKernelGGL(wino_in_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, x, V, B, H, W, C);
 }
 void launch_wino_out(const float* Mo, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
