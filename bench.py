@@ -23,6 +23,11 @@ import time
 
 import numpy as np
 
+# the lanes are HIP streams: give the runtime enough hardware queues for them (before HIP initialises;
+# see ocr_amd/crnn/_capi.py _more_hw_queues)
+if not os.environ.get("CRNN_KEEP_HW_QUEUES") and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -76,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--lanes", type=int, default=3, help="independent stream/workspace lanes per GPU")
+    ap.add_argument("--lanes", type=int, default=4, help="independent stream/workspace lanes per GPU")
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="fp32 = the headline, parity-exact path; bf16 = bf16 MFMA inputs, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -52,7 +52,7 @@ typedef struct {
   int32_t leaky_relu; /* leakyRelu */
   int32_t lstm;       /* lstmFlag */
   int32_t device;     /* HIP device ordinal (config.GPUID) */
-  int32_t lanes;      /* independent (stream, workspace) lanes crnn_forward_device rotates over; 0 -> 1, max 4 */
+  int32_t lanes;      /* independent (stream, workspace) lanes crnn_forward_device rotates over; 0 -> 1, max 8 */
   int32_t precision;  /* CRNN_FP32 (exact fp32 MFMA; the parity path) or CRNN_BF16 (bf16 MFMA inputs, fp32
                          accumulate; reports character agreement, not held to the 1e-3 logit bound) */
   int32_t reserved;

@@ -36,7 +36,7 @@ struct DevBuf {
   size_t cap = 0;
 };
 
-constexpr int MAX_LANES = 4;
+constexpr int MAX_LANES = 8;
 constexpr int MAXK = 32;
 
 struct Lane {
