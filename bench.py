@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="fp32 = the headline, parity-exact path; bf16 = bf16 MFMA inputs, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="one batch at a time (for rocprofv3 --kernel-trace --stats: per-kernel durations that are "
+                         "not stretched by the other lanes, with the tile shapes the pipelined run uses)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -149,6 +152,8 @@ def main():
         texts = None
         for k in range(nsteps):
             launch(k)
+            if args.serial:
+                model.synchronize()
             if k >= NL:
                 texts = collect(k - NL)
         for k in range(max(0, nsteps - NL), nsteps):
@@ -264,6 +269,12 @@ def main():
         # or pass the MFMA peak; roofline.achieved above counts the FLOPs the MFMAs actually execute.
         "pipeline_tflops": round(FLOP_PER_LINE * value / 1e12, 2),
         "pipeline_effective_frac_of_mfma_peak": round(FLOP_PER_LINE * value / 1e12 / (peak * world), 4),
+        # FLOPs the MFMAs execute per step (every GEMM launch + the recurrences) / step time: what the whole
+        # pipeline, lanes overlapped, sustains.  roofline.achieved is the dominant kernel measured ALONE on the
+        # device; with several lanes the library picks the 128x128 Winograd tile, which is slower alone at this
+        # batch (2.25 rounds of one block per CU) but faster in the pipeline, where other lanes fill its tail.
+        "pipeline_executed_mfma_tflops": round(sum(acc[n][1] for n in order if n != "conv0_pool0") * world
+                                               / (elapsed / args.steps) / 1e12, 2),
         "kernels": kernels,
     }
     if not args.no_cpu_baseline:

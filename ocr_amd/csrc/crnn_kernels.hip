@@ -294,7 +294,8 @@ constexpr int WBM = 128, WBN = 64, WBUF = (WBM + WBN) * LDT;
 
 // component (a,b) = comp complete: o[i][j] += AT[i][a] * AT[j][b] * acc (coefficients 0 / +-1, exact
 // as an fma; wave-uniform branches: 7 of the 16 components touch one output only, 4 touch all four)
-__device__ __forceinline__ void wino_flush(f32x16 (&acc)[2], f32x16 (&o)[2][2][2], int& kc, int& comp) {
+template <int MT>
+__device__ __forceinline__ void wino_flush(f32x16 (&acc)[MT], f32x16 (&o)[2][2][MT], int& kc, int& comp) {
   const int ka = comp >> 2, kb = comp & 3;
   const float ra0 = ka < 3 ? 1.f : 0.f, ra1 = ka == 0 ? 0.f : (ka == 1 ? 1.f : -1.f);
   const float cb0 = kb < 3 ? 1.f : 0.f, cb1 = kb == 0 ? 0.f : (kb == 1 ? 1.f : -1.f);
@@ -306,13 +307,13 @@ __device__ __forceinline__ void wino_flush(f32x16 (&acc)[2], f32x16 (&o)[2][2][2
       const float c = i ? (j ? c11 : c10) : (j ? c01 : c00);
       if (c != 0.f) {
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++)
+        for (int mt = 0; mt < MT; mt++)
 #pragma unroll
           for (int r = 0; r < 16; r++) o[i][j][mt][r] = __builtin_fmaf(c, acc[mt][r], o[i][j][mt][r]);
       }
     }
 #pragma unroll
-  for (int mt = 0; mt < 2; mt++)
+  for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
   kc = 0;
@@ -320,7 +321,8 @@ __device__ __forceinline__ void wino_flush(f32x16 (&acc)[2], f32x16 (&o)[2][2][2
 }
 
 // bias + activation + width mask, NHWC (or the max over the tile when pooling)
-__device__ __forceinline__ void wino_epilogue(const f32x16 (&o)[2][2][2], const WinoGemm& p, int m0, int n0, int wm,
+template <int MT>
+__device__ __forceinline__ void wino_epilogue(const f32x16 (&o)[2][2][MT], const WinoGemm& p, int m0, int n0, int wm,
                                               int wn, int lane) {
   const int th = p.H >> 1, tw = (p.W + 1) >> 1;
   const int n = n0 + wn * 32 + (lane & 31);
@@ -340,10 +342,10 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&o)[2][2][2], const 
     if (r >= d) { q++; r -= d; }
   };
 #pragma unroll
-  for (int mt = 0; mt < 2; mt++)
+  for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) {
-      const int t0 = m0 + wm * 64 + mt * 32 + 8 * rq + 4 * (lane >> 5);
+      const int t0 = m0 + wm * (32 * MT) + mt * 32 + 8 * rq + 4 * (lane >> 5);
       int q, tx, b, ty;
       divmod(t0, tw, inv_tw, q, tx);
       divmod(q, th, inv_th, b, ty);
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
   };
 
   int kc = 0, comp = 0;
-  auto flush = [&]() { wino_flush(acc, o, kc, comp); };
+  auto flush = [&]() { wino_flush<2>(acc, o, kc, comp); };
   // steps are numbered 0 .. nit-1 (nit is even); step s is staged through register set s & 1 and
   // LDS buffer s & 1.  Entering iteration `it`: LDS holds step it, set (it+1)&1 holds / is
   // receiving step it+1, and step it+2 is issued into the other set as soon as that set was stored.
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
     if (++kc == nk) flush();
   }
 
-  wino_epilogue(o, p, m0, n0, wm, wn, lane);
+  wino_epilogue<2>(o, p, m0, n0, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -518,23 +520,25 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
 // the first fragment reads of the next step run under 8 MFMAs.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-constexpr int WSA = WBM * 32;   // floats per A stage (unpadded; the B stage is 32 floats x tile N)
 
 // NWN = waves along N: 2 -> 128 x 64 tile, 256 threads, two blocks per CU; 4 -> 128 x 128 tile, 512 threads,
 // one block per CU (a third fewer loads per MFMA, half the L2 -> LDS traffic).
-template <int NWN>
-__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino_gemm_dma_kernel(const WinoGemm p) {
-  constexpr int NT = 128 * NWN, TBN = 32 * NWN, SB = TBN * 32, NLA = 1024 / NT;   // threads, tile N, floats per B stage, A loads per thread
-  __shared__ __attribute__((aligned(1024))) float smem[3 * (WSA + SB)];   // [B0 B1 B2 | A0 A1 A2], 72 / 96 KB
+// MT = 32-row MFMA tiles per wave along M: 2 -> 128-tile blocks; 1 -> 64 x 64 blocks with 80 accumulator
+// registers per lane, three blocks (12 waves) per CU and four times as many, smaller work units.
+template <int NWN, int MT>
+__global__ __launch_bounds__(128 * NWN, MT == 1 ? 3 : (NWN == 2 ? 2 : 1)) void wino_gemm_dma_kernel(const WinoGemm p) {
+  // threads, tile M / N, floats per A / B stage, A loads per thread
+  constexpr int NT = 128 * NWN, TBM = 64 * MT, TBN = 32 * NWN, SA = TBM * 32, SB = TBN * 32, NLA = TBM * 8 / NT;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];   // [B0 B1 B2 | A0 A1 A2], 72 / 96 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int ntn = p.N / TBN;
-  const int nblk = ((p.ntile + WBM - 1) / WBM) * ntn;
+  const int nblk = ((p.ntile + TBM - 1) / TBM) * ntn;
   const int chunk = gridDim.x >> 3;
   const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (L >= nblk) return;
   const int bm = L / ntn, bn = L - bm * ntn;
-  const int m0 = bm * WBM, n0 = bn * TBN;
+  const int m0 = bm * TBM, n0 = bn * TBN;
 
   // loader: LDS chunk position P = i * 256 + tid holds (row, kchunk) given by the swizzle
   unsigned aoff[NLA], boff[2];
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino_gemm_dma_ker
   auto gload = [&](int stage) {
     const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
     const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
-    const unsigned sa = lds0 + (3 * SB + stage * WSA) * 4, sb = lds0 + stage * SB * 4;
+    const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
 #pragma unroll
     for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], l_k0 * 4);
 #pragma unroll
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino_gemm_dma_ker
   // fragment addresses (floats, inside a stage) per k-group; a1 = a0 + 32 rows = + 1024 floats
   int aaddr[4], baddr[4];
   {
-    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
+    const int Ra = wm * (32 * MT) + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
 #pragma unroll
     for (int kg = 0; kg < 4; kg++) {
       aaddr[kg] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (2 * kg + h)) ^ ((Ra >> 1) & 15)) << 2);
@@ -593,29 +597,31 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino_gemm_dma_ker
     }
   }
 
-  f32x16 acc[2], o[2][2][2];
+  f32x16 acc[MT], o[2][2][MT];
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    acc[0][r] = 0.f; acc[1][r] = 0.f;
+  for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int r = 0; r < 16; r++) {
+      acc[mt][r] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 2; j++) { o[i][j][0][r] = 0.f; o[i][j][1][r] = 0.f; }
-  }
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) o[i][j][mt][r] = 0.f;
+    }
   int kc = 0, comp = 0;
   f32x4 a0[2], a1[2], b0[2];
   auto frag = [&](int stage, int kg, int set) {
-    const float* sa = smem + 3 * SB + stage * WSA;
+    const float* sa = smem + 3 * SB + stage * SA;
     const float* sb = smem + stage * SB;
     a0[set] = *(const f32x4*)(sa + aaddr[kg]);
-    a1[set] = *(const f32x4*)(sa + aaddr[kg] + 1024);
+    if (MT == 2) a1[set] = *(const f32x4*)(sa + aaddr[kg] + 1024);
     b0[set] = *(const f32x4*)(sb + baddr[kg]);
   };
   auto mfma8 = [&](int set) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[set][j], b0[set][j], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[set][j], b0[set][j], acc[1], 0, 0, 0);
+      if (MT == 2) acc[MT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[set][j], b0[set][j], acc[MT - 1], 0, 0, 0);
     }
   };
   // one K step on stage st; on entry fragment set 0 holds k-group 0 of this step
@@ -635,21 +641,22 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino_gemm_dma_ker
     __builtin_amdgcn_sched_barrier(0);
     // publish the next step: its 6 loads were issued two steps ago (the 6 of the step after it may
     // still be in flight); every wave has read all of stage st into registers by now
-    __builtin_amdgcn_s_waitcnt(NWN == 2 ? 0x0076 : 0x0074);   // vmcnt(one step's loads: 6 / 4) lgkmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // vmcnt(one step's loads) lgkmcnt(0)
     __syncthreads();
     gload(st);                            // step +3 reuses this stage
     frag(nx, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     mfma8(1);
     __builtin_amdgcn_sched_barrier(0);
-    if (++kc == nk) wino_flush(acc, o, kc, comp);
+    if (++kc == nk) wino_flush<MT>(acc, o, kc, comp);
   };
 
   const int nit = 16 * nk;
   gload(0);
   gload(1);
   gload(2);
-  __builtin_amdgcn_s_waitcnt(NWN == 2 ? 0x0F7C : 0x0F78);   // vmcnt(2 steps' loads): step 0 landed
+  constexpr int LPS = NLA + 2;               // loads per K step per wave (4 or 6)
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));   // vmcnt(2 steps' loads): step 0 landed
   __syncthreads();
   frag(0, 0, 0);
   int it = 0;
@@ -662,24 +669,39 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino_gemm_dma_ker
   if (it < nit) step(std::integral_constant<int, 0>{});
   if (it + 1 < nit) step(std::integral_constant<int, 1>{});
   __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): no LDS write may be in flight when the block ends
-  wino_epilogue(o, p, m0, n0, wm, wn, lane);
+  wino_epilogue<MT>(o, p, m0, n0, wm, wn, lane);
 }
 
 void launch_wino_gemm(const WinoGemm& p, hipStream_t s) {
-  const int nblk = ((p.ntile + WBM - 1) / WBM) * (p.N / WBN);
-  // CRNN_WINO_DMA: 0 register-staged kernel, 1 128x64 tiles, 2 128x128 tiles, unset: per launch, whichever
-  // tile shape fills its block slots better (512 slots of 128x64 or 256 of 128x128; the wide tile is ~3 %
-  // faster when both fill their last round, and much slower when its last round is mostly empty)
+  // CRNN_WINO_DMA: 0 register-staged kernel, 1 128x64 tiles, 2 128x128 tiles, 3 64x64 tiles; unset: per launch.
+  // Alone on the device (one lane) the shape with the best estimate  peak * (1 - tail * (1 - fill)),
+  // fill = units / (rounds * slots): at full rounds 128x128 (256 slots, one block per CU) is ~3 % faster and
+  // 64x64 (768 slots) ~6 % slower than 128x64 (512 slots); a partly empty last round costs the two-or-three-
+  // blocks-per-CU shapes about a third of its emptiness (the last blocks have their CUs to themselves) and the
+  // one-block-per-CU shape all of it.  With several lanes the 128x128 shape wins regardless (+4 % on the whole
+  // pipeline): it leaves 64 KB of LDS and half the wave slots of every CU to the kernels of the other lanes,
+  // which also fill its last round.  Measured at batch 256 / 227: tools/exp_batch.py, bench.py.
   static const int dma = getenv("CRNN_WINO_DMA") ? atoi(getenv("CRNN_WINO_DMA")) : -1;
-  const dim3 g(8 * ((nblk + 7) / 8));
-  const int nb2 = ((p.ntile + WBM - 1) / WBM) * (p.N / 128);
-  bool wide = dma == 2;
-  if (dma < 0 && p.N % 128 == 0) {
-    const double e2 = (double)nblk / (((nblk + 511) / 512) * 512.0), e4 = (double)nb2 / (((nb2 + 255) / 256) * 256.0);
-    wide = e4 >= e2 && e4 >= 0.9;
+  const int mt128 = (p.ntile + 127) / 128, mt64 = (p.ntile + 63) / 64;
+  const int units[4] = {0, mt128 * (p.N / 64), mt128 * (p.N / 128), mt64 * (p.N / 64)};
+  int shape = dma;
+  if (dma < 0) {
+    const int slots[4] = {0, 512, 256, 768};
+    const double peak[4] = {0, 1.0, 1.03, 0.94}, tail[4] = {0, 1.0 / 3, 1.0, 1.0 / 3};
+    double best = 0;
+    for (int k = 1; k <= 3; k++) {
+      if (k == 2 && p.N % 128) continue;
+      const double fill = (double)units[k] / ((double)((units[k] + slots[k] - 1) / slots[k]) * slots[k]);
+      const double est = peak[k] * (1.0 - tail[k] * (1.0 - fill));
+      if (est > best) { best = est; shape = k; }
+    }
+    if (p.shared && p.N % 128 == 0) shape = 2;
   }
-  if (wide && p.N % 128 == 0) hipLaunchKernelGGL(wino_gemm_dma_kernel<4>, dim3(8 * ((nb2 + 7) / 8)), dim3(512), 0, s, p);
-  else if (dma) hipLaunchKernelGGL(wino_gemm_dma_kernel<2>, g, dim3(256), 0, s, p);
+  if (shape == 2 && p.N % 128) shape = 1;
+  const dim3 g(8 * ((units[shape > 0 ? shape : 1] + 7) / 8));
+  if (shape == 3) hipLaunchKernelGGL((wino_gemm_dma_kernel<2, 1>), g, dim3(256), 0, s, p);
+  else if (shape == 2) hipLaunchKernelGGL((wino_gemm_dma_kernel<4, 2>), g, dim3(512), 0, s, p);
+  else if (shape == 1) hipLaunchKernelGGL((wino_gemm_dma_kernel<2, 2>), g, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(wino_gemm_kernel, g, dim3(256), 0, s, p);
 }
 

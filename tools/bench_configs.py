@@ -28,7 +28,7 @@ def main():
     out = {"precision": args.precision}
 
     # ---------------- config 3
-    en = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish, device=0, lanes=3, precision=args.precision)
+    en = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish, device=0, lanes=4, precision=args.precision)
     en.load_state_dict(synth_state_dict(65, seed=0))
     rs = np.random.RandomState(3)
     widths = [int(w) for w in rs.choice(np.arange(64, 1025, 32), size=args.lines)]
