@@ -277,7 +277,7 @@ def main():
                                                / (elapsed / args.steps) / 1e12, 2),
         "kernels": kernels,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
         cb, cpu_texts = cpu_baseline(host_lines[0], sd, keys.alphabetChinese)
         out["cpu_baseline"] = cb
         same = sum(a == b for a, b in zip(first_texts, cpu_texts))
