@@ -38,7 +38,7 @@ class CRNN(object):
     """Same surface as ``crnn.network_torch.CRNN``; inference only."""
 
     def __init__(self, imgH, nc, nclass, nh, leakyRelu=False, lstmFlag=True, GPU=False, alphabet=None, device=None,
-                 lanes=1, precision='fp32'):
+                 lanes=2, precision='fp32'):
         assert imgH % 16 == 0, 'imgH has to be a multiple of 16'
         if imgH != 32 or nc != 1 or nh != 256:
             raise ValueError("the HIP path implements the shipped configuration: imgH=32, nc=1, nh=256")
@@ -197,9 +197,22 @@ class CRNN(object):
                 for i, t in zip(bucket, self._texts(lab, ln)):
                     out[keep[i]] = t
             return out
-        for bucket in width_buckets(widths, max_batch, width_spread, min_cols):
+        buckets = width_buckets(widths, max_batch, width_spread, min_cols)
+
+        def one(bucket):
             lab, ln, _, _, _ = self._run([arrs[i] for i in bucket], pad_mode)
-            for i, t in zip(bucket, self._texts(lab, ln)):
+            return self._texts(lab, ln)
+        nthreads = min(len(buckets), self.lanes, 4)
+        if nthreads > 1:
+            # buckets run concurrently on different lanes of the handle (ctypes releases the GIL during
+            # the call): one bucket's packing / upload / copy-back overlaps another's device work
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(nthreads) as ex:
+                results = list(ex.map(one, buckets))
+        else:
+            results = [one(b) for b in buckets]
+        for bucket, texts in zip(buckets, results):
+            for i, t in zip(bucket, texts):
                 out[i] = t
         return out
 

@@ -52,6 +52,7 @@ struct Lane {
   DevBuf pre;        // preprocessing scratch (sources, temp, coefficients, jobs)
   DevBuf io;         // per-call small buffers (outputs of the host path)
   DevBuf stage;      // PINNED HOST memory: packed sources on their way to the device
+  std::mutex mu;     // held by whichever call is using this lane's stream and buffers
   float* st[11] = {};          // where the stages of the last run live (crnn_debug_stage)
   size_t st_floats[11] = {};
 };
@@ -61,7 +62,6 @@ struct Lane {
 struct crnn_handle {
   crnn_config cfg{};
   std::mutex mu;
-  mutable std::string err = "";
   bool loaded = false;
 
   // host copies of the prepared weights (uploaded lazily, re-uploaded after fork)
@@ -106,14 +106,21 @@ struct crnn_handle {
   Lane lanes[MAX_LANES];
   int nlanes = 1;
   int next_lane = 0;
-  Lane* cur = &lanes[0];     // lane of the call in progress (set under mu)
+  int next_host_lane = 0;
   Lane* last = &lanes[0];    // lane of the most recent network run (timing / debug queries)
 };
 
 namespace {
 
+// The lane a call works on and its error text are per calling thread: host-path calls of different
+// threads run concurrently on different lanes of one handle (gunicorn.conf.py:24 runs two threads per
+// worker over the one global CRNN object).  Locking order: handle mutex, then lane mutex.
+thread_local Lane* tl_cur = nullptr;
+thread_local std::string tl_err;
+
 int fail(const crnn_handle* h, int code, const std::string& msg) {
-  if (h) h->err = msg;
+  (void)h;
+  tl_err = msg;
   return code;
 }
 
@@ -127,7 +134,7 @@ int fail(const crnn_handle* h, int code, const std::string& msg) {
 int ensure_buf(crnn_handle* h, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return 0;
   if (b.p) {
-    HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+    HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
     HIPCHK(h, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -142,7 +149,7 @@ int ensure_buf(crnn_handle* h, DevBuf& b, size_t bytes) {
 int ensure_host(crnn_handle* h, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return 0;
   if (b.p) {
-    HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+    HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
     HIPCHK(h, hipHostFree(b.p));
     b.p = nullptr;
     b.cap = 0;
@@ -197,10 +204,10 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       for (int i = 0; i < 5; i++) HIPCHK(h, hipEventCreate(&L.ev[i]));
       for (int i = 0; i <= MAXK; i++) HIPCHK(h, hipEventCreate(&L.kev[i]));
     }
-    upload_norm_lut(h->lut, h->cur->stream);
+    upload_norm_lut(h->lut, tl_cur->stream);
     HIPCHK(h, hipMalloc((void**)&h->d_zero_bias, 512 * sizeof(float)));
     HIPCHK(h, hipMemset(h->d_zero_bias, 0, 512 * sizeof(float)));
-    HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+    HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
     h->dev_pid = getpid();
     h->dev_ready = true;
   } else {
@@ -359,10 +366,10 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
 // Per-launch profiling (crnn_set_profiling): an event after every launch; name, algorithmic
 // FLOPs (2*MACs) and algorithmic bytes (compulsory reads + writes) of the launch it closes.
 void kmark(crnn_handle* h, const char* name, double flop, double bytes) {
-  if (!h->kprof || h->cur->nk >= MAXK) return;
-  h->cur->kname[h->cur->nk] = name; h->cur->kflop[h->cur->nk] = flop; h->cur->kbytes[h->cur->nk] = bytes;
-  h->cur->nk++;
-  (void)hipEventRecord(h->cur->kev[h->cur->nk], h->cur->stream);
+  if (!h->kprof || tl_cur->nk >= MAXK) return;
+  tl_cur->kname[tl_cur->nk] = name; tl_cur->kflop[tl_cur->nk] = flop; tl_cur->kbytes[tl_cur->nk] = bytes;
+  tl_cur->nk++;
+  (void)hipEventRecord(tl_cur->kev[tl_cur->nk], tl_cur->stream);
 }
 
 // out_bf16 only matters on the bf16 path (which GEMM outputs feed another GEMM)
@@ -375,8 +382,8 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
   p.M = M; p.N = N; p.K = K; p.ldc = N;
   p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
   p.pmax = pmax; p.pidx = pidx;
-  if (b16) launch_conv_gemm_bf16(p, out_bf16, h->cur->stream);
-  else launch_conv_gemm(p, h->cur->stream);
+  if (b16) launch_conv_gemm_bf16(p, out_bf16, tl_cur->stream);
+  else launch_conv_gemm(p, tl_cur->stream);
   const double es = b16 ? 2.0 : 4.0;
   kmark(h, name, 2.0 * M * N * K,
         es * ((double)M * K + (double)N * K) + (C ? ((b16 && out_bf16) ? 2.0 : 4.0) * M * N : 8.0 * M * ((N + 127) / 128)));
@@ -395,7 +402,7 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
                                    {"", "conv1_wout", "conv2_wout", "conv3_wout", "conv4_wout", "conv5_wout", ""}};
     const int Co = NM[layer];
     const long tiles = (long)n * (Hin / 2) * ((Win + 1) / 2);
-    hipStream_t s = h->cur->stream;
+    hipStream_t s = tl_cur->stream;
     launch_wino_in((const float*)A, wino_v, n, Hin, Win, Cin, s);
     kmark(h, wn[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 16.0 * tiles * Cin));
     if (h->wino_fused) {
@@ -429,8 +436,8 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
   p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
   p.ks = KS[layer]; p.pad = KS[layer] == 3 ? 1 : 0;
   p.act = h->cfg.leaky_relu ? 2 : 1;
-  if (b16) launch_conv_gemm_bf16(p, true, h->cur->stream);
-  else launch_conv_gemm(p, h->cur->stream);
+  if (b16) launch_conv_gemm_bf16(p, true, tl_cur->stream);
+  else launch_conv_gemm(p, tl_cur->stream);
   const double es = b16 ? 2.0 : 4.0;
   kmark(h, names[layer], 2.0 * p.M * p.N * p.K,
         es * ((double)n * Hin * Win * Cin + (double)p.N * p.K + (double)p.M * p.N));
@@ -453,12 +460,12 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       wl[2 * n + i] = w2;            // conv2, conv3
       wl[3 * n + i] = w3;            // conv4, conv5 ; also T_i
     }
-    HIPCHK(h, hipMemcpyAsync(p.wl, wl.data(), sizeof(int32_t) * 4 * n, hipMemcpyHostToDevice, h->cur->stream));
-    HIPCHK(h, hipStreamSynchronize(h->cur->stream));  // wl is a stack temporary
+    HIPCHK(h, hipMemcpyAsync(p.wl, wl.data(), sizeof(int32_t) * 4 * n, hipMemcpyHostToDevice, tl_cur->stream));
+    HIPCHK(h, hipStreamSynchronize(tl_cur->stream));  // wl is a stack temporary
     m_p0 = p.wl; m_c1 = p.wl + n; m_w2 = p.wl + 2 * n; m_w3 = p.wl + 3 * n; tlen = m_w3;
   }
-  hipStream_t s = h->cur->stream;
-  HIPCHK(h, hipEventRecord(h->cur->ev[1], s));
+  hipStream_t s = tl_cur->stream;
+  HIPCHK(h, hipEventRecord(tl_cur->ev[1], s));
   const double dn = n;
   const bool b16 = h->cfg.precision == CRNN_BF16;
   const double es = b16 ? 2.0 : 4.0;
@@ -481,7 +488,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   else launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
   kmark(h, "pool3", 0, es * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
   conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T);
-  HIPCHK(h, hipEventRecord(h->cur->ev[2], s));
+  HIPCHK(h, hipEventRecord(tl_cur->ev[2], s));
   const int M = n * g.T;
   const double recflop = 2.0 * M * 2 * 1024 * 256;
   const double recbytes = 4.0 * M * 2048 + es * ((double)M * 512 + 2 * 1024 * 256);
@@ -502,16 +509,16 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     gemm(h, "classifier", p.seq, h->d_lin_w, h->db_lin_w, h->d_lin_b, want_logits ? p.logits : nullptr, M,
          h->cfg.nclass, 512, false, p.pmax, p.pidx);
   }
-  HIPCHK(h, hipEventRecord(h->cur->ev[3], s));
+  HIPCHK(h, hipEventRecord(tl_cur->ev[3], s));
   // the classifier's epilogue left per-tile (max, index) partials: finish the arg-max over tiles
   const int ntn = (h->cfg.nclass + 127) / 128;
   launch_argmax_partials(p.pmax, p.pidx, p.raw, M, ntn, s);
   kmark(h, "argmax", 0, 8.0 * M * ntn + 4.0 * M);
   launch_ctc(p.raw, tlen, d_lab, d_len, n, g.T, s);
   kmark(h, "ctc", 0, 4.0 * (2.0 * M + n));
-  HIPCHK(h, hipEventRecord(h->cur->ev[4], s));
-  h->cur->ev_valid = true;
-  h->last = h->cur;
+  HIPCHK(h, hipEventRecord(tl_cur->ev[4], s));
+  tl_cur->ev_valid = true;
+  h->last = tl_cur;
   HIPCHK(h, hipGetLastError());
   // remember where the stages live
   float* st[11] = {p.p0, p.p1, p.c2, p.p2, p.c4, p.p3, p.seq, p.mid, p.rec0, p.rec1, p.logits};
@@ -519,7 +526,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
                    (size_t)n * 4 * g.W3 * 256, (size_t)n * 4 * g.W3 * 512, (size_t)n * 2 * g.W4 * 512,
                    (size_t)M * 512, (size_t)M * 256, (size_t)M * 512, (size_t)M * 512,
                    (size_t)M * h->cfg.nclass};
-  for (int i = 0; i < 11; i++) { h->cur->st[i] = st[i]; h->cur->st_floats[i] = sz[i]; }
+  for (int i = 0; i < 11; i++) { tl_cur->st[i] = st[i]; tl_cur->st_floats[i] = sz[i]; }
   return 0;
 }
 
@@ -529,9 +536,9 @@ int prepare_plan(crnn_handle* h, const Geo& g, Plan& p) {
   if (big >= 2147000000.0)
     return fail(h, CRNN_ERR_ARG, "batch too large (an activation tensor exceeds 2 GiB): split the batch");
   Plan probe = make_plan(h, g, nullptr);
-  int rc = ensure_buf(h, h->cur->arena, probe.bytes);
+  int rc = ensure_buf(h, tl_cur->arena, probe.bytes);
   if (rc) return rc;
-  p = make_plan(h, g, (char*)h->cur->arena.p);
+  p = make_plan(h, g, (char*)tl_cur->arena.p);
   return 0;
 }
 
@@ -580,9 +587,9 @@ int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* he
     if (J.dw > max_dw) max_dw = J.dw;
   }
   // pack the sources (rows may be strided views of a page: ocr_context.py:307, vat_detect.py:318)
-  int rc = ensure_host(h, h->cur->stage, src_bytes + 16);
+  int rc = ensure_host(h, tl_cur->stage, src_bytes + 16);
   if (rc) return rc;
-  uint8_t* src = (uint8_t*)h->cur->stage.p;
+  uint8_t* src = (uint8_t*)tl_cur->stage.p;
   for (int j = 0; j < nb && !rect_off; j++) {
     const int i = sel[j];
     const size_t rowb = (size_t)widths[i] * channels[i];
@@ -591,18 +598,18 @@ int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* he
   }
   const size_t a = (src_bytes + 255) / 256 * 256, b = (tmp_bytes + 255) / 256 * 256;
   const size_t c = (coef.size() * 4 + 255) / 256 * 256, d = (jobs.size() * sizeof(ResizeJob) + 255) / 256 * 256;
-  rc = ensure_buf(h, h->cur->pre, a + b + c + d);
+  rc = ensure_buf(h, tl_cur->pre, a + b + c + d);
   if (rc) return rc;
-  uint8_t* d_src = (uint8_t*)h->cur->pre.p;
+  uint8_t* d_src = (uint8_t*)tl_cur->pre.p;
   uint8_t* d_tmp = d_src + a;
   if (rect_off) d_src = (uint8_t*)h->page.p;
   int32_t* d_coef = (int32_t*)(d_tmp + b);
   ResizeJob* d_jobs = (ResizeJob*)((char*)d_coef + c);
-  hipStream_t s = h->cur->stream;
+  hipStream_t s = tl_cur->stream;
   if (!rect_off && src_bytes) HIPCHK(h, hipMemcpyAsync(d_src, src, src_bytes, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(d_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(ResizeJob), hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipEventRecord(h->cur->ev[0], s));
+  HIPCHK(h, hipEventRecord(tl_cur->ev[0], s));
   launch_resize_h(d_src, d_jobs, d_coef, d_tmp, nb, max_th, max_dw, s);
   launch_resize_v(d_src, d_jobs, d_coef, d_tmp, d_x, nb, Wp, s);
   HIPCHK(h, hipStreamSynchronize(s));  // host staging vectors go out of scope
@@ -806,7 +813,8 @@ int crnn_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* h
                     int32_t* out_w) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  h->cur = &h->lanes[0];
+  tl_cur = &h->lanes[0];
+  std::lock_guard<std::mutex> lane_lk(h->lanes[0].mu);
   if (n <= 0 || !out_host || !out_w) return fail(h, CRNN_ERR_ARG, "bad arguments");
   int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
   if (rc) return rc;
@@ -819,14 +827,14 @@ int crnn_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* h
   }
   if ((rc = ensure_device(h, false))) return rc;
   const size_t bytes = (size_t)n * 32 * wp * sizeof(float);
-  if ((rc = ensure_buf(h, h->cur->arena, bytes))) return rc;
-  if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, wp, (float*)h->cur->arena.p)))
+  if ((rc = ensure_buf(h, tl_cur->arena, bytes))) return rc;
+  if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, wp, (float*)tl_cur->arena.p)))
     return rc;
-  HIPCHK(h, hipMemcpy(out_host, h->cur->arena.p, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out_host, tl_cur->arena.p, bytes, hipMemcpyDeviceToHost));
   return 0;
 }
 
-// crnn_predict_batch / crnn_predict_rects after argument checks (lock held, h->cur set)
+// crnn_predict_batch / crnn_predict_rects after argument checks (lock held, tl_cur set)
 static int predict_core(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
                         const int32_t* row_strides, const int32_t* channels, const int64_t* rect_off, int32_t n,
                         int32_t pad_mode, int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len,
@@ -851,18 +859,18 @@ static int predict_core(crnn_handle* h, const uint8_t* const* imgs, const int32_
   Plan p;
   if ((rc = prepare_plan(h, g, p))) return rc;
   const size_t nT = (size_t)g.n * g.T;
-  if ((rc = ensure_buf(h, h->cur->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
-  int32_t* d_lab = (int32_t*)h->cur->io.p;
+  if ((rc = ensure_buf(h, tl_cur->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
+  int32_t* d_lab = (int32_t*)tl_cur->io.p;
   int32_t* d_len = d_lab + ((nT + 63) / 64) * 64;
   if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, Wp, p.x, rect_off))) return rc;
   std::vector<int32_t> wv(dw.begin(), dw.end());
   const bool uniform = pad_mode == CRNN_PAD_REFERENCE;
   if ((rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len, out_logits != nullptr))) return rc;
   std::vector<int32_t> lab(nT), raw(nT), len(g.n);
-  HIPCHK(h, hipMemcpyAsync(lab.data(), d_lab, nT * 4, hipMemcpyDeviceToHost, h->cur->stream));
-  HIPCHK(h, hipMemcpyAsync(raw.data(), p.raw, nT * 4, hipMemcpyDeviceToHost, h->cur->stream));
-  HIPCHK(h, hipMemcpyAsync(len.data(), d_len, (size_t)g.n * 4, hipMemcpyDeviceToHost, h->cur->stream));
-  HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+  HIPCHK(h, hipMemcpyAsync(lab.data(), d_lab, nT * 4, hipMemcpyDeviceToHost, tl_cur->stream));
+  HIPCHK(h, hipMemcpyAsync(raw.data(), p.raw, nT * 4, hipMemcpyDeviceToHost, tl_cur->stream));
+  HIPCHK(h, hipMemcpyAsync(len.data(), d_len, (size_t)g.n * 4, hipMemcpyDeviceToHost, tl_cur->stream));
+  HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
   std::vector<float> lg;
   if (out_logits) {
     lg.resize(nT * (size_t)h->cfg.nclass);
@@ -887,12 +895,29 @@ int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t
                        int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t,
                        float* out_logits) {
   if (!h) return CRNN_ERR_ARG;
-  std::lock_guard<std::mutex> lk(h->mu);
-  h->cur = &h->lanes[0];
   if (n <= 0 || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
   if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
   int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
   if (rc) return rc;
+  // Concurrent callers (threads of one worker) each take a lane of their own: the handle mutex is held only
+  // to bring the device up and to pick the lane, the lane mutex for the run itself.
+  std::unique_lock<std::mutex> lane_lk;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    tl_cur = &h->lanes[0];
+    if ((rc = ensure_device(h))) return rc;
+    int lane = -1;
+    for (int i = 0; i < h->nlanes && lane < 0; i++) {
+      std::unique_lock<std::mutex> t(h->lanes[i].mu, std::try_to_lock);
+      if (t.owns_lock()) { lane = i; lane_lk = std::move(t); }
+    }
+    if (lane < 0) {   // all busy: queue behind one of them, round robin
+      lane = h->next_host_lane;
+      h->next_host_lane = (h->next_host_lane + 1) % h->nlanes;
+    }
+    tl_cur = &h->lanes[lane];
+  }
+  if (!lane_lk.owns_lock()) lane_lk = std::unique_lock<std::mutex>(tl_cur->mu);
   return predict_core(h, imgs, heights, widths, row_strides, channels, nullptr, n, pad_mode, tmax, out_raw, out_lab,
                       out_len, out_t, out_logits);
 }
@@ -901,7 +926,8 @@ int crnn_set_page(crnn_handle* h, const uint8_t* page, int32_t height, int32_t w
                   int32_t channels) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  h->cur = &h->lanes[0];
+  tl_cur = &h->lanes[0];
+  std::lock_guard<std::mutex> lane_lk(h->lanes[0].mu);
   if (!page || height <= 0 || width <= 0) return fail(h, CRNN_ERR_ARG, "empty page");
   if (channels != 1 && channels != 3) return fail(h, CRNN_ERR_ARG, "channels must be 1 (gray) or 3 (BGR)");
   if (row_stride < width * channels) return fail(h, CRNN_ERR_ARG, "row stride smaller than a row");
@@ -911,12 +937,12 @@ int crnn_set_page(crnn_handle* h, const uint8_t* page, int32_t height, int32_t w
   // any lane may still be reading the previous page
   for (int i = 0; i < h->nlanes; i++) HIPCHK(h, hipStreamSynchronize(h->lanes[i].stream));
   if ((rc = ensure_buf(h, h->page, bytes + 256))) return rc;
-  if ((rc = ensure_host(h, h->cur->stage, bytes))) return rc;
-  uint8_t* st = (uint8_t*)h->cur->stage.p;
+  if ((rc = ensure_host(h, tl_cur->stage, bytes))) return rc;
+  uint8_t* st = (uint8_t*)tl_cur->stage.p;
   if ((size_t)row_stride == rowb) memcpy(st, page, bytes);
   else for (int y = 0; y < height; y++) memcpy(st + (size_t)y * rowb, page + (size_t)y * row_stride, rowb);
-  HIPCHK(h, hipMemcpyAsync(h->page.p, st, bytes, hipMemcpyHostToDevice, h->cur->stream));
-  HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+  HIPCHK(h, hipMemcpyAsync(h->page.p, st, bytes, hipMemcpyHostToDevice, tl_cur->stream));
+  HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
   h->page_h = height; h->page_w = width; h->page_ch = channels;
   return 0;
 }
@@ -925,7 +951,8 @@ int crnn_predict_rects(crnn_handle* h, const int32_t* rects, int32_t n, int32_t 
                        int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t, float* out_logits) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  h->cur = &h->lanes[0];
+  tl_cur = &h->lanes[0];
+  std::lock_guard<std::mutex> lane_lk(h->lanes[0].mu);
   if (n <= 0 || !rects || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
   if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
   if (!h->page.p || h->page_h <= 0) return fail(h, CRNN_ERR_STATE, "no page: call crnn_set_page first");
@@ -959,7 +986,8 @@ int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_
       if (widths[i] < 8 || widths[i] > w) return fail(h, CRNN_ERR_ARG, "line width outside [8, w]");
   const int lane = h->next_lane;
   h->next_lane = (h->next_lane + 1) % h->nlanes;
-  h->cur = &h->lanes[lane];
+  tl_cur = &h->lanes[lane];
+  std::lock_guard<std::mutex> lane_lk(h->lanes[lane].mu);
   int rc = ensure_device(h);
   if (rc) return rc;
   const Geo g(n, w);
@@ -968,17 +996,17 @@ int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_
   int32_t* d_w = nullptr;
   if (widths) {
     d_w = p.wl + 4 * (size_t)n;
-    HIPCHK(h, hipMemcpyAsync(d_w, widths, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->cur->stream));
+    HIPCHK(h, hipMemcpyAsync(d_w, widths, sizeof(int32_t) * n, hipMemcpyHostToDevice, tl_cur->stream));
   }
-  HIPCHK(h, hipEventRecord(h->cur->ev[0], h->cur->stream));
-  h->cur->nk = 0;
-  if (h->kprof) HIPCHK(h, hipEventRecord(h->cur->kev[0], h->cur->stream));
-  launch_normalize(d_gray, p.x, d_w, n, w, w, h->cur->stream);
+  HIPCHK(h, hipEventRecord(tl_cur->ev[0], tl_cur->stream));
+  tl_cur->nk = 0;
+  if (h->kprof) HIPCHK(h, hipEventRecord(tl_cur->kev[0], tl_cur->stream));
+  launch_normalize(d_gray, p.x, d_w, n, w, w, tl_cur->stream);
   kmark(h, "normalize", 0, (double)n * 32 * w * 5.0);
   if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
   if (d_raw)
-    HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, h->cur->stream));
-  if (sync) HIPCHK(h, hipStreamSynchronize(h->cur->stream));
+    HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, tl_cur->stream));
+  if (sync) HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
   return lane;
 }
 
@@ -986,7 +1014,8 @@ int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const
                      float* out_host, int64_t out_floats) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  h->cur = &h->lanes[0];
+  tl_cur = &h->lanes[0];
+  std::lock_guard<std::mutex> lane_lk(h->lanes[0].mu);
   if (!x || n <= 0 || w < 4 || stage < 0 || stage > 10 || !out_host) return fail(h, CRNN_ERR_ARG, "bad arguments");
   int rc = ensure_device(h);
   if (rc) return rc;
@@ -994,24 +1023,24 @@ int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const
   Plan p;
   if ((rc = prepare_plan(h, g, p))) return rc;
   const size_t nT = (size_t)g.n * g.T;
-  if ((rc = ensure_buf(h, h->cur->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
-  int32_t* d_lab = (int32_t*)h->cur->io.p;
+  if ((rc = ensure_buf(h, tl_cur->io, (nT + g.n) * sizeof(int32_t) + 512))) return rc;
+  int32_t* d_lab = (int32_t*)tl_cur->io.p;
   int32_t* d_len = d_lab + ((nT + 63) / 64) * 64;
-  HIPCHK(h, hipMemcpyAsync(p.x, x, sizeof(float) * (size_t)n * 32 * w, hipMemcpyHostToDevice, h->cur->stream));
-  HIPCHK(h, hipEventRecord(h->cur->ev[0], h->cur->stream));
+  HIPCHK(h, hipMemcpyAsync(p.x, x, sizeof(float) * (size_t)n * 32 * w, hipMemcpyHostToDevice, tl_cur->stream));
+  HIPCHK(h, hipEventRecord(tl_cur->ev[0], tl_cur->stream));
   if ((rc = run_network(h, g, p, widths, d_lab, d_len, true))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->cur->stream));
-  if ((size_t)out_floats < h->cur->st_floats[stage]) return fail(h, CRNN_ERR_ARG, "out_host too small for this stage");
+  HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
+  if ((size_t)out_floats < tl_cur->st_floats[stage]) return fail(h, CRNN_ERR_ARG, "out_host too small for this stage");
   if (h->cfg.precision == CRNN_BF16 && stage != 10) {   // stored as bf16 on the device: widen for the caller
-    std::vector<uint16_t> tmp(h->cur->st_floats[stage]);
-    HIPCHK(h, hipMemcpy(tmp.data(), h->cur->st[stage], tmp.size() * 2, hipMemcpyDeviceToHost));
+    std::vector<uint16_t> tmp(tl_cur->st_floats[stage]);
+    HIPCHK(h, hipMemcpy(tmp.data(), tl_cur->st[stage], tmp.size() * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); i++) {
       const uint32_t u = (uint32_t)tmp[i] << 16;
       memcpy(&out_host[i], &u, 4);
     }
     return 0;
   }
-  HIPCHK(h, hipMemcpy(out_host, h->cur->st[stage], h->cur->st_floats[stage] * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out_host, tl_cur->st[stage], tl_cur->st_floats[stage] * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1070,7 +1099,7 @@ int crnn_last_kernel_times(crnn_handle* h, int32_t cap, const char** names, floa
   return n;
 }
 
-const char* crnn_last_error(const crnn_handle* h) { return h ? h->err.c_str() : "null handle"; }
+const char* crnn_last_error(const crnn_handle* h) { return h ? tl_err.c_str() : "null handle"; }
 
 void crnn_destroy(crnn_handle* h) {
   if (!h) return;

@@ -55,7 +55,7 @@ def main():
                       "note": "65-class head, widths uniform over {64..1024 step 32}, per-line masked batches (== predict)"}
 
     # ---------------- config 5 (crop replay)
-    zh = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1, precision=args.precision)
+    zh = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=3, precision=args.precision)
     zh.load_state_dict(synth_state_dict(5530, seed=0))
     G = np.load(os.path.join(ROOT, "tests", "golden", "crnn_golden.npz"))
     shapes = [G[k].shape for k in G.files if k.startswith("inv/") and k.endswith("/bgr")]

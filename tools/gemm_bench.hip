@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
   const int bm = blockIdx.x / ntn, bn = blockIdx.x - bm * ntn;
   const int m0 = bm * BM, n0 = bn * BN;
   const int lrow = tid >> 3, lk = (tid & 7) * 4;
-  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-  if (EPI == 5) t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, r0 = 0;
+  if (EPI == 5) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   const int hw = p.Hout * p.Wout;
   // descriptor bases: A shifted back by the padding so that every voffset is >= 0
   const long shift = ((long)p.pad * p.Win + p.pad) * p.Cin;
@@ -380,6 +380,9 @@ __global__ __launch_bounds__(256, MINW) void gemm_b(const ConvGemm p) {
     if (threadIdx.x == 0) {
       unsigned long long* st = (unsigned long long*)p.wvalid + (size_t)blockIdx.x * 4;
       st[0] = t0; st[1] = t1; st[2] = t2; st[3] = t3;
+      // core clock over this block: shader cycles per 100 MHz tick
+      const unsigned long long r3 = __builtin_amdgcn_s_memrealtime();
+      st[1] = r3 - r0;   // (the prologue stamp is not reported in this mode)
     }
   }
 }
@@ -488,6 +491,9 @@ int main(int argc, char** argv) {
       for (int i = 0; i < grid; i++) { a += st[i*4+1]-st[i*4]; b += st[i*4+2]-st[i*4+1]; c += st[i*4+3]-st[i*4+2];
         if (st[i*4] < tmin) tmin = st[i*4]; if (st[i*4+3] > tmax) tmax = st[i*4+3]; }
       printf("stamps (s_memtime ticks, 100 MHz?): prologue %.0f  loop %.0f  epilogue %.0f  per block; kernel span %llu\n", a / grid, b / grid, c / grid, tmax - tmin);
+      double cyc = 0, ticks = 0;
+      for (int i = 0; i < grid; i++) { cyc += (double)(st[i*4+3] - st[i*4]); ticks += (double)st[i*4+1]; }
+      printf("core clock during the GEMM (all blocks, s_memtime / s_memrealtime): %.0f MHz\n", cyc / ticks * 100);
       p.wvalid = nullptr;
     }
     for (int ns = 2; ns <= 1; ns++) {
