@@ -1057,6 +1057,7 @@ void* crnn_stream(crnn_handle* h, int32_t lane) {
   if (!h || lane < 0) return nullptr;
   std::lock_guard<std::mutex> lk(h->mu);
   if (lane >= h->nlanes) return nullptr;
+  tl_cur = &h->lanes[0];
   if (ensure_device(h, false)) return nullptr;
   return (void*)h->lanes[lane].stream;
 }

@@ -182,3 +182,25 @@ print("P:" + parent)
     assert out.returncode == 0 and len(lines) == 2, (out.stdout, out.stderr[-2000:])
     assert lines[0].startswith("C:") and lines[1].startswith("P:"), lines
     assert lines[0][2:] == lines[1][2:] and len(lines[0]) > 2
+
+
+@pytest.mark.gpu
+def test_first_call_on_a_fresh_thread_and_handle(synth_en):
+    """Entry points that do not run the network (stream query, synchronize, timing) must work as the very
+    first call on a handle and from a thread that has never used it (the current lane is per thread)."""
+    import threading
+    from ocr_amd.crnn import keys
+    from ocr_amd.crnn.network_hip import CRNN
+    m = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish, device=0, lanes=3)
+    m.load_state_dict(synth_en)
+    assert m.stream_ptr(2)
+    m.synchronize()
+    res = {}
+
+    def other():
+        res["stream"] = m.stream_ptr(1)
+        res["text"] = m.predict_lines([np.full((32, 100), 200, np.uint8)])
+        m.synchronize()
+    t = threading.Thread(target=other)
+    t.start(); t.join()
+    assert res["stream"] and res["text"] == m.predict_lines([np.full((32, 100), 200, np.uint8)])
