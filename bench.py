@@ -223,7 +223,9 @@ def main():
                 "ms_per_launch_avg": round(ms / max(1, len(names)), 4)}
     fams = []
     if wino_names:
-        fams.append(family("wino_gemm_dma_kernel", wino_names, "Winograd F(2x2,3x3) GEMM + output transform, executed MFMA FLOPs"))
+        fams.append(family("wino_gemm_dma_kernel", wino_names,
+                           "Winograd F(2x2,3x3) GEMM + output transform, executed MFMA FLOPs; a launch here is one layer = "
+                           "the 128x128-tile launch over the full rounds plus the small-tile launch over the remaining tiles"))
     fams.append(family(direct_kernel, direct_names, "implicit-GEMM conv + LSTM input projections + embedding + classifier"))
     fams.sort(key=lambda f: -f["ms_per_step"])
     dom = fams[0]

@@ -410,7 +410,6 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
       w.V = wino_v; w.U = h->d_wino[layer]; w.bias = h->d_conv_b[layer]; w.y = (float*)C; w.wvalid = wvalid;
       w.ntile = (int)tiles; w.N = Co; w.Cin = Cin; w.B = n; w.H = Hin; w.W = Win;
       w.act = h->cfg.leaky_relu ? 2 : 1; w.pool = pool_out ? 1 : 0;
-      w.shared = h->nlanes > 1;
       if (pool_out) w.y = pool_out;
       launch_wino_gemm(w, s);
       kmark(h, pool_out ? "conv1_pool1" : wn[1][layer], 2.0 * 16 * tiles * Co * Cin,

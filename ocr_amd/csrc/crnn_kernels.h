@@ -157,7 +157,7 @@ struct WinoGemm {
   float* y;               // NHWC [B,H,W,N]  (pool: [B,H/2,W/2,N])
   const int32_t* wvalid;  // per-line valid output width (pre-pool columns) or nullptr
   int ntile, N, Cin, B, H, W, act, pool;
-  int shared;             // != 0: kernels of other lanes run beside this one (tile-shape choice, host side only)
+  int m_off, m_cnt;       // tiles [m_off, m_off + m_cnt) are this launch's share (set by launch_wino_gemm)
 };
 void launch_wino_gemm(const WinoGemm& p, hipStream_t s);
 

@@ -352,7 +352,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&o)[2][2][MT], const
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int r = rq * 4 + rr;
-        if (t0 + rr < p.ntile) {
+        if (t0 + rr < p.m_off + p.m_cnt) {
           const int wv = p.wvalid ? p.wvalid[b] : p.W;
           float v[2][2];
 #pragma unroll
@@ -533,12 +533,12 @@ __global__ __launch_bounds__(128 * NWN, MT == 1 ? 3 : (NWN == 2 ? 2 : 1)) void w
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int ntn = p.N / TBN;
-  const int nblk = ((p.ntile + TBM - 1) / TBM) * ntn;
+  const int nblk = ((p.m_cnt + TBM - 1) / TBM) * ntn;
   const int chunk = gridDim.x >> 3;
   const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (L >= nblk) return;
   const int bm = L / ntn, bn = L - bm * ntn;
-  const int m0 = bm * TBM, n0 = bn * TBN;
+  const int m0 = p.m_off + bm * TBM, n0 = bn * TBN;
 
   // loader: LDS chunk position P = i * 256 + tid holds (row, kchunk) given by the swizzle
   unsigned aoff[NLA], boff[2];
@@ -672,37 +672,58 @@ __global__ __launch_bounds__(128 * NWN, MT == 1 ? 3 : (NWN == 2 ? 2 : 1)) void w
   wino_epilogue<MT>(o, p, m0, n0, wm, wn, lane);
 }
 
+// one launch of one tile shape (0 register-staged 128x64, 1 DMA 128x64, 2 DMA 128x128, 3 DMA 64x64) over the
+// Winograd tiles [m_off, m_off + m_cnt)
+static void launch_wino_shape(WinoGemm q, int shape, int m_off, int m_cnt, hipStream_t s) {
+  q.m_off = m_off; q.m_cnt = m_cnt;
+  if (shape == 2 && q.N % 128) shape = 1;
+  const int tbm = shape == 3 ? 64 : 128, tbn = shape == 2 ? 128 : 64;
+  const int units = ((m_cnt + tbm - 1) / tbm) * (q.N / tbn);
+  const dim3 g(8 * ((units + 7) / 8));
+  if (shape == 3) hipLaunchKernelGGL((wino_gemm_dma_kernel<2, 1>), g, dim3(256), 0, s, q);
+  else if (shape == 2) hipLaunchKernelGGL((wino_gemm_dma_kernel<4, 2>), g, dim3(512), 0, s, q);
+  else if (shape == 1) hipLaunchKernelGGL((wino_gemm_dma_kernel<2, 2>), g, dim3(256), 0, s, q);
+  else hipLaunchKernelGGL(wino_gemm_kernel, g, dim3(256), 0, s, q);
+}
+
+// Tile shapes.  128x128 (512 threads, one block per CU, 256 slots) has the fewest loads per MFMA and is the
+// fastest while it fills its rounds (MfmaUtil 0.85-0.88 inside a round), but a partly filled last round costs
+// it all of that round's emptiness: at batch 256 its 576 tiles of conv5 are 2.25 rounds.  So the full rounds go
+// to the 128x128 shape and the remaining tiles to a second launch with a small shape whose units spread over
+// all CUs -- 64x64 (three blocks per CU) for up to 384 128x64-units' worth, 128x64 beyond (and 128x128 again if
+// they fill 85 % of a round).  Without a full
+// 128x128 round (small batches) one launch of the shape with the best estimate  peak * (1 - tail * (1 - fill)),
+// fill = units / (rounds * slots), peak 1.0 / 0.94 and tail 1/3 for 128x64 (512 slots) / 64x64 (768 slots).
+// CRNN_WINO_DMA = 0..3 forces one shape for everything (tests/test_hip_variants.py runs them all).
 void launch_wino_gemm(const WinoGemm& p, hipStream_t s) {
-  // CRNN_WINO_DMA: 0 register-staged kernel, 1 128x64 tiles, 2 128x128 tiles, 3 64x64 tiles; unset: per launch.
-  // Alone on the device (one lane) the shape with the best estimate  peak * (1 - tail * (1 - fill)),
-  // fill = units / (rounds * slots): at full rounds 128x128 (256 slots, one block per CU) is ~3 % faster and
-  // 64x64 (768 slots) ~6 % slower than 128x64 (512 slots); a partly empty last round costs the two-or-three-
-  // blocks-per-CU shapes about a third of its emptiness (the last blocks have their CUs to themselves) and the
-  // one-block-per-CU shape all of it.  With several lanes the 128x128 shape wins regardless (+4 % on the whole
-  // pipeline): it leaves 64 KB of LDS and half the wave slots of every CU to the kernels of the other lanes,
-  // which also fill its last round.  Measured at batch 256 / 227: tools/exp_batch.py, bench.py.
   static const int dma = getenv("CRNN_WINO_DMA") ? atoi(getenv("CRNN_WINO_DMA")) : -1;
-  const int mt128 = (p.ntile + 127) / 128, mt64 = (p.ntile + 63) / 64;
-  const int units[4] = {0, mt128 * (p.N / 64), mt128 * (p.N / 128), mt64 * (p.N / 64)};
-  int shape = dma;
-  if (dma < 0) {
-    const int slots[4] = {0, 512, 256, 768};
-    const double peak[4] = {0, 1.0, 1.03, 0.94}, tail[4] = {0, 1.0 / 3, 1.0, 1.0 / 3};
-    double best = 0;
-    for (int k = 1; k <= 3; k++) {
-      if (k == 2 && p.N % 128) continue;
-      const double fill = (double)units[k] / ((double)((units[k] + slots[k] - 1) / slots[k]) * slots[k]);
-      const double est = peak[k] * (1.0 - tail[k] * (1.0 - fill));
-      if (est > best) { best = est; shape = k; }
+  if (dma >= 0) { launch_wino_shape(p, dma > 3 ? 1 : dma, 0, p.ntile, s); return; }
+  if (p.N % 128 == 0) {
+    const int per_round = (256 / (p.N / 128)) * 128;        // tiles one full round of 128x128 blocks covers
+    const int full = (p.ntile / per_round) * per_round;
+    if (full > 0) {
+      launch_wino_shape(p, 2, 0, full, s);
+      const int rem = p.ntile - full;
+      if (rem > 0) {
+        const int u1 = ((rem + 127) / 128) * (p.N / 64);
+        // an almost full round stays with the big shape
+        launch_wino_shape(p, rem * 100 >= per_round * 85 ? 2 : (u1 <= 384 ? 3 : 1), full, rem, s);
+      }
+      return;
     }
-    if (p.shared && p.N % 128 == 0) shape = 2;
+    if (p.ntile * 100 >= per_round * 85) { launch_wino_shape(p, 2, 0, p.ntile, s); return; }
   }
-  if (shape == 2 && p.N % 128) shape = 1;
-  const dim3 g(8 * ((units[shape > 0 ? shape : 1] + 7) / 8));
-  if (shape == 3) hipLaunchKernelGGL((wino_gemm_dma_kernel<2, 1>), g, dim3(256), 0, s, p);
-  else if (shape == 2) hipLaunchKernelGGL((wino_gemm_dma_kernel<4, 2>), g, dim3(512), 0, s, p);
-  else if (shape == 1) hipLaunchKernelGGL((wino_gemm_dma_kernel<2, 2>), g, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(wino_gemm_kernel, g, dim3(256), 0, s, p);
+  const int units[4] = {0, ((p.ntile + 127) / 128) * (p.N / 64), 0, ((p.ntile + 63) / 64) * (p.N / 64)};
+  const int slots[4] = {0, 512, 0, 768};
+  const double peak[4] = {0, 1.0, 0, 0.94};
+  int shape = 1;
+  double best = 0;
+  for (int k = 1; k <= 3; k += 2) {
+    const double fill = (double)units[k] / ((double)((units[k] + slots[k] - 1) / slots[k]) * slots[k]);
+    const double est = peak[k] * (1.0 - (1.0 - fill) / 3.0);
+    if (est > best) { best = est; shape = k; }
+  }
+  launch_wino_shape(p, shape, 0, p.ntile, s);
 }
 
 static unsigned ew_blocks_w(long total) {
