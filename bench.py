@@ -242,7 +242,8 @@ def main():
         with open(tp) as f:
             tj = json.load(f)
         if all(n in tj for n in gemm_names):
-            traffic = sum(tj[n]["hbm_bytes"] for n in gemm_names) / len(gemm_names)
+            # a Winograd layer is two launches (full rounds + "<layer>_tail"): count both
+            traffic = sum(tj[n]["hbm_bytes"] + tj.get(n + "_tail", {}).get("hbm_bytes", 0.0) for n in gemm_names) / len(gemm_names)
             traffic_src = "profiles/" + os.path.basename(tp)
 
     out = {

@@ -14,8 +14,15 @@ ORDER_WINO = ["normalize", "conv0_pool0", "conv1", "pool1", "conv2", "conv3_win"
 ORDER_FUSED = ["normalize", "conv0_pool0", "conv1_win", "conv1_pool1", "conv2_win", "conv2", "conv3_win", "conv3", "pool2",
                "conv4_win", "conv4", "conv5_win", "conv5", "pool3",
                "conv6", "lstm0_ih", "lstm0_rec", "emb0", "lstm1_ih", "lstm1_rec", "classifier", "argmax", "ctc"]
+# hybrid: every Winograd layer is two launches at batch 256 (128x128 tiles over the full rounds, then a
+# small-tile launch over the remaining tiles, "<layer>_tail")
+ORDER_HYBRID = []
+for _k in ORDER_FUSED:
+    ORDER_HYBRID.append(_k)
+    if _k in ("conv1_pool1", "conv2", "conv3", "conv4", "conv5"):
+        ORDER_HYBRID.append(_k + "_tail")
 MODE = sys.argv[4] if len(sys.argv) > 4 else "direct"
-ORDER = {"wino": ORDER_WINO, "fused": ORDER_FUSED}.get(MODE, ORDER_DIRECT)
+ORDER = {"wino": ORDER_WINO, "fused": ORDER_FUSED, "hybrid": ORDER_HYBRID}.get(MODE, ORDER_DIRECT)
 
 
 def per_launch(d, counter):
