@@ -122,6 +122,14 @@ CRNN_API int crnn_set_page(crnn_handle* h, const uint8_t* page, int32_t height, 
 CRNN_API int crnn_predict_rects(crnn_handle* h, const int32_t* rects, int32_t n, int32_t pad_mode,
                        int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t,
                        float* out_logits);
+/* Both steps in one call, for concurrent callers (the two request threads of a gunicorn worker,
+ * gunicorn.conf.py:24, each with its own page): takes any free lane of the handle, uploads the page into
+ * that lane's page buffer and recognises the rectangles there, so two pages are in flight at once.
+ * crnn_set_page / crnn_predict_rects above always use lane 0 and serialise. */
+CRNN_API int crnn_predict_page(crnn_handle* h, const uint8_t* page, int32_t height, int32_t width,
+                      int32_t row_stride, int32_t channels, const int32_t* rects, int32_t n,
+                      int32_t pad_mode, int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len,
+                      int32_t* out_t, float* out_logits);
 
 /* The same path for lines already resident in device memory at height 32 (the layout the
  * width-bucketing scheduler and bench.py use): d_gray uint8 [n,32,w] device pointer; widths

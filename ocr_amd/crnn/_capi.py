@@ -17,7 +17,7 @@ PAD_PER_LINE, PAD_REFERENCE = 0, 1
 FP32, BF16 = 0, 1
 
 SYMBOLS = ["crnn_create", "crnn_load_weights", "crnn_resized_width", "crnn_out_len", "crnn_preprocess",
-           "crnn_predict_batch", "crnn_set_page", "crnn_predict_rects", "crnn_forward_device", "crnn_debug_stage", "crnn_synchronize", "crnn_stream", "crnn_lanes",
+           "crnn_predict_batch", "crnn_set_page", "crnn_predict_rects", "crnn_predict_page", "crnn_forward_device", "crnn_debug_stage", "crnn_synchronize", "crnn_stream", "crnn_lanes",
            "crnn_last_timing", "crnn_set_profiling", "crnn_last_kernel_times", "crnn_last_error", "crnn_destroy"]
 
 
@@ -106,6 +106,8 @@ def lib():
     L.crnn_set_page.argtypes = [vp, vp, i32, i32, i32, i32]
     L.crnn_predict_rects.restype = C.c_int
     L.crnn_predict_rects.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.crnn_predict_page.restype = C.c_int
+    L.crnn_predict_page.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]
     L.crnn_forward_device.restype = C.c_int
     L.crnn_forward_device.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i32]
     L.crnn_debug_stage.restype = C.c_int

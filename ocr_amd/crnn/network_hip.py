@@ -217,32 +217,28 @@ class CRNN(object):
         return out
 
     # ------------------------------------------- crops as rectangles of one page
-    def set_page(self, page):
-        """Upload a page (HxWx3 uint8 BGR as cv2.imread gives it, or HxW gray; any row stride) once;
-        it stays in device memory until the next set_page."""
+    @staticmethod
+    def _page_array(page):
         a = np.asarray(page)
         if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3) or a.size == 0:
-            raise ValueError("set_page expects a non-empty HxW or HxWx3 uint8 array, got %s %s" % (a.dtype, a.shape))
+            raise ValueError("expected a non-empty HxW or HxWx3 uint8 page, got %s %s" % (a.dtype, a.shape))
         ch = 1 if a.ndim == 2 else 3
         if a.strides[-1] != 1 or (a.ndim == 3 and a.strides[1] != 3) or a.strides[0] < a.shape[1] * ch:
             a = np.ascontiguousarray(a)
+        return a, ch
+
+    def set_page(self, page):
+        """Upload a page (HxWx3 uint8 BGR as cv2.imread gives it, or HxW gray; any row stride) once;
+        it stays in device memory (lane 0) until the next set_page."""
+        a, ch = self._page_array(page)
         self._page_shape = a.shape[:2]
         _capi.check(self._h, self._lib.crnn_set_page(self._h, a.ctypes.data, a.shape[0], a.shape[1], a.strides[0], ch))
 
-    def predict_rects(self, rects, max_batch=256, width_spread=1.25, min_cols=24576):
-        """Texts of the crops page[y1:y2, x1:x2] for rects = [(x1, y1, x2, y2), ...] of the page given to
-        set_page -- what ``[self.ocr(page[y1:y2, x1:x2]) for ...]`` returns (ocr_context.py:119,307 fed by
-        vat_detect.py:318), without cutting or uploading the crops: the resize reads the resident page.
-        Width-bucketed like predict_lines; ends beyond the page are clipped as numpy slicing does."""
+    def _rect_plan(self, rects, shape, max_batch, width_spread, min_cols):
         r = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4)
-        n = len(r)
-        if n == 0:
-            return []
         if (r < 0).any():
             raise ValueError("negative rectangle coordinate")
-        if self._page_shape is None:
-            raise RuntimeError("no page: call set_page first")
-        ph, pw = self._page_shape
+        ph, pw = shape
         hh = np.minimum(r[:, 3], ph) - r[:, 1]
         ww = np.minimum(r[:, 2], pw) - r[:, 0]
         if (hh <= 0).any():
@@ -252,28 +248,57 @@ class CRNN(object):
         if min(widths) <= 0:
             raise ValueError("height and width must be > 0")
         from .batching import width_buckets
-        out = [None] * n
         exact = 1.0 if self.leakyRelu else width_spread
-        for bucket in width_buckets(widths, max_batch, exact, 0 if self.leakyRelu else min_cols):
-            if self.leakyRelu and widths[bucket[0]] < 8:
-                for i in bucket:
-                    out[i] = ''
-                continue
-            rb = np.ascontiguousarray(r[bucket])
-            tmax = max(1, self._lib.crnn_out_len(max(widths[i] for i in bucket)))
-            lab = np.zeros((len(bucket), tmax), np.int32)
-            ln = np.zeros(len(bucket), np.int32)
-            mode = _capi.PAD_REFERENCE if self.leakyRelu else _capi.PAD_PER_LINE
-            _capi.check(self._h, self._lib.crnn_predict_rects(self._h, rb.ctypes.data, len(bucket), mode, tmax, None,
-                                                              lab.ctypes.data, ln.ctypes.data, None, None))
-            for i, t in zip(bucket, self._texts(lab, ln)):
+        return r, widths, width_buckets(widths, max_batch, exact, 0 if self.leakyRelu else min_cols)
+
+    def _rect_bucket(self, r, widths, bucket, call):
+        """One bucket of rectangles through ``call(rects_ptr, n, mode, tmax, lab_ptr, len_ptr)``."""
+        if self.leakyRelu and widths[bucket[0]] < 8:
+            return [''] * len(bucket)
+        rb = np.ascontiguousarray(r[bucket])
+        tmax = max(1, self._lib.crnn_out_len(max(widths[i] for i in bucket)))
+        lab = np.zeros((len(bucket), tmax), np.int32)
+        ln = np.zeros(len(bucket), np.int32)
+        mode = _capi.PAD_REFERENCE if self.leakyRelu else _capi.PAD_PER_LINE
+        _capi.check(self._h, call(rb.ctypes.data, len(bucket), mode, tmax, lab.ctypes.data, ln.ctypes.data))
+        return self._texts(lab, ln)
+
+    def predict_rects(self, rects, max_batch=256, width_spread=1.25, min_cols=24576):
+        """Texts of the crops page[y1:y2, x1:x2] for rects = [(x1, y1, x2, y2), ...] of the page given to
+        set_page -- what ``[self.ocr(page[y1:y2, x1:x2]) for ...]`` returns (ocr_context.py:119,307 fed by
+        vat_detect.py:318), without cutting or uploading the crops: the resize reads the resident page.
+        Width-bucketed like predict_lines; ends beyond the page are clipped as numpy slicing does."""
+        if len(rects) == 0:
+            return []
+        if self._page_shape is None:
+            raise RuntimeError("no page: call set_page first")
+        r, widths, buckets = self._rect_plan(rects, self._page_shape, max_batch, width_spread, min_cols)
+        out = [None] * len(r)
+        for bucket in buckets:
+            texts = self._rect_bucket(r, widths, bucket, lambda rp, n, mode, tmax, lab, ln: self._lib.crnn_predict_rects(
+                self._h, rp, n, mode, tmax, None, lab, ln, None, None))
+            for i, t in zip(bucket, texts):
                 out[i] = t
         return out
 
-    def ocr_page(self, page, rects):
-        """set_page + predict_rects."""
-        self.set_page(page)
-        return self.predict_rects(rects)
+    def ocr_page(self, page, rects, max_batch=256, width_spread=1.25, min_cols=24576):
+        """Texts of page[y1:y2, x1:x2] for every rectangle: ``[self.ocr(page[y1:y2, x1:x2]) for ...]`` with one
+        upload of the page.  When the rectangles make one device batch (the usual case for a page's worth of
+        crops) this is ONE library call that takes any free lane, so concurrent callers with different pages
+        overlap on the device; otherwise set_page + predict_rects (lane 0)."""
+        if len(rects) == 0:
+            return []
+        a, ch = self._page_array(page)
+        r, widths, buckets = self._rect_plan(rects, a.shape[:2], max_batch, width_spread, min_cols)
+        if len(buckets) != 1:
+            self.set_page(a)
+            return self.predict_rects(rects, max_batch, width_spread, min_cols)
+        texts = self._rect_bucket(r, widths, buckets[0], lambda rp, n, mode, tmax, lab, ln: self._lib.crnn_predict_page(
+            self._h, a.ctypes.data, a.shape[0], a.shape[1], a.strides[0], ch, rp, n, mode, tmax, None, lab, ln, None, None))
+        out = [None] * len(r)
+        for i, t in zip(buckets[0], texts):      # the bucket is in width order
+            out[i] = t
+        return out
 
     # ------------------------------------------------------------- debug / test
     def forward_logits(self, images, pad_mode=_capi.PAD_PER_LINE):

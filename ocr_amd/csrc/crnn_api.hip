@@ -53,6 +53,8 @@ struct Lane {
   DevBuf io;         // per-call small buffers (outputs of the host path)
   DevBuf stage;      // PINNED HOST memory: packed sources on their way to the device
   std::mutex mu;     // held by whichever call is using this lane's stream and buffers
+  DevBuf page;       // resident page of this lane (crnn_set_page uses lane 0, crnn_predict_page any free lane)
+  int page_h = 0, page_w = 0, page_ch = 0;
   float* st[11] = {};          // where the stages of the last run live (crnn_debug_stage)
   size_t st_floats[11] = {};
 };
@@ -71,9 +73,6 @@ struct crnn_handle {
   // Winograd F(2x2,3x3) weights U[16][Cout][Cin] for the layers in wino_mask (fp32 path only)
   std::vector<float> h_wino[7];
   unsigned wino_mask = 0;
-  // resident page for crnn_set_page / crnn_predict_rects (crops are rectangles of one page)
-  DevBuf page;
-  int page_h = 0, page_w = 0, page_ch = 0;
   bool wino_fused = true;   // GEMM + output transform in one kernel (CRNN_WINO_FUSED=0: separate kernels)
   // bf16 copies (precision == CRNN_BF16): conv1..6, W_ih, embeddings / linear, packed W_hh
   std::vector<uint16_t> hb_conv_w[7], hb_wih[2], hb_whhp[2], hb_emb_w[2], hb_lin_w;
@@ -188,8 +187,8 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       L.ev_valid = false;
       L.nk = 0;
       L.arena = DevBuf(); L.pre = DevBuf(); L.io = DevBuf(); L.stage = DevBuf();
+      L.page = DevBuf(); L.page_h = L.page_w = L.page_ch = 0;
     }
-    h->page = DevBuf(); h->page_h = h->page_w = h->page_ch = 0;
   }
   if (!h->dev_ready) {
     int ndev = 0;
@@ -544,7 +543,7 @@ int prepare_plan(crnn_handle* h, const Geo& g, Plan& p) {
 // Gray conversion + Pillow-exact resize + normalise for a set of host images,
 // into d_x [nb,32,Wp].  sel lists the image indices to process, dw their
 // resized widths.
-// With rect_off != nullptr the sources are rectangles of the page already in HBM (h->page): rect_off[i]
+// With rect_off != nullptr the sources are rectangles of the lane's page already in HBM: rect_off[i]
 // is the byte offset of rectangle i's first pixel, rows are page rows, nothing is uploaded but the
 // coefficient tables.
 int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
@@ -562,7 +561,7 @@ int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* he
     const int sh = heights[i], sw = widths[i], ch = channels[i];
     J.sh = sh; J.sw = sw; J.ch = ch; J.dw = dw[j];
     if (rect_off) {
-      J.stride = h->page_w * h->page_ch;
+      J.stride = tl_cur->page_w * tl_cur->page_ch;
       J.src_off = rect_off[i];
     } else {
       J.stride = sw * ch;  // repacked tightly on upload
@@ -601,7 +600,7 @@ int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* he
   if (rc) return rc;
   uint8_t* d_src = (uint8_t*)tl_cur->pre.p;
   uint8_t* d_tmp = d_src + a;
-  if (rect_off) d_src = (uint8_t*)h->page.p;
+  if (rect_off) d_src = (uint8_t*)tl_cur->page.p;
   int32_t* d_coef = (int32_t*)(d_tmp + b);
   ResizeJob* d_jobs = (ResizeJob*)((char*)d_coef + c);
   hipStream_t s = tl_cur->stream;
@@ -889,22 +888,14 @@ static int predict_core(crnn_handle* h, const uint8_t* const* imgs, const int32_
   return 0;
 }
 
-int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
-                       const int32_t* row_strides, const int32_t* channels, int32_t n, int32_t pad_mode,
-                       int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t,
-                       float* out_logits) {
-  if (!h) return CRNN_ERR_ARG;
-  if (n <= 0 || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
-  if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
-  int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
-  if (rc) return rc;
-  // Concurrent callers (threads of one worker) each take a lane of their own: the handle mutex is held only
-  // to bring the device up and to pick the lane, the lane mutex for the run itself.
-  std::unique_lock<std::mutex> lane_lk;
+// Concurrent callers (threads of one worker) each take a lane of their own: the handle mutex is held only
+// to bring the device up and to pick the lane, the lane mutex (returned locked) for the run itself.
+static int pick_lane(crnn_handle* h, std::unique_lock<std::mutex>& lane_lk) {
   {
     std::lock_guard<std::mutex> lk(h->mu);
     tl_cur = &h->lanes[0];
-    if ((rc = ensure_device(h))) return rc;
+    int rc = ensure_device(h);
+    if (rc) return rc;
     int lane = -1;
     for (int i = 0; i < h->nlanes && lane < 0; i++) {
       std::unique_lock<std::mutex> t(h->lanes[i].mu, std::try_to_lock);
@@ -917,8 +908,68 @@ int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t
     tl_cur = &h->lanes[lane];
   }
   if (!lane_lk.owns_lock()) lane_lk = std::unique_lock<std::mutex>(tl_cur->mu);
+  return 0;
+}
+
+int crnn_predict_batch(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heights, const int32_t* widths,
+                       const int32_t* row_strides, const int32_t* channels, int32_t n, int32_t pad_mode,
+                       int32_t tmax, int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t,
+                       float* out_logits) {
+  if (!h) return CRNN_ERR_ARG;
+  if (n <= 0 || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
+  if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
+  int rc = check_images(h, imgs, heights, widths, row_strides, channels, n);
+  if (rc) return rc;
+  std::unique_lock<std::mutex> lane_lk;
+  if ((rc = pick_lane(h, lane_lk))) return rc;
   return predict_core(h, imgs, heights, widths, row_strides, channels, nullptr, n, pad_mode, tmax, out_raw, out_lab,
                       out_len, out_t, out_logits);
+}
+
+// page -> the current lane's page buffer (through its pinned stage)
+static int upload_page(crnn_handle* h, const uint8_t* page, int32_t height, int32_t width, int32_t row_stride,
+                       int32_t channels) {
+  if (!page || height <= 0 || width <= 0) return fail(h, CRNN_ERR_ARG, "empty page");
+  if (channels != 1 && channels != 3) return fail(h, CRNN_ERR_ARG, "channels must be 1 (gray) or 3 (BGR)");
+  if (row_stride < width * channels) return fail(h, CRNN_ERR_ARG, "row stride smaller than a row");
+  Lane& L = *tl_cur;
+  const size_t rowb = (size_t)width * channels, bytes = rowb * height;
+  HIPCHK(h, hipStreamSynchronize(L.stream));   // the lane may still be reading its previous page
+  int rc;
+  if ((rc = ensure_buf(h, L.page, bytes + 256))) return rc;
+  if ((rc = ensure_host(h, L.stage, bytes))) return rc;
+  uint8_t* st = (uint8_t*)L.stage.p;
+  if ((size_t)row_stride == rowb) memcpy(st, page, bytes);
+  else for (int y = 0; y < height; y++) memcpy(st + (size_t)y * rowb, page + (size_t)y * row_stride, rowb);
+  HIPCHK(h, hipMemcpyAsync(L.page.p, st, bytes, hipMemcpyHostToDevice, L.stream));
+  HIPCHK(h, hipStreamSynchronize(L.stream));   // the stage is reused by the next upload
+  L.page_h = height; L.page_w = width; L.page_ch = channels;
+  return 0;
+}
+
+// rectangles of the current lane's page through the network
+static int rects_core(crnn_handle* h, const int32_t* rects, int32_t n, int32_t pad_mode, int32_t tmax,
+                      int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t, float* out_logits) {
+  const Lane& L = *tl_cur;
+  if (!L.page.p || L.page_h <= 0) return fail(h, CRNN_ERR_STATE, "no page: call crnn_set_page first");
+  // im0[y1:y2, x1:x2] (vat_detect.py:318): ends are clipped to the page like a numpy slice; negative
+  // coordinates (which numpy would wrap) are refused
+  std::vector<int32_t> hh(n), ww(n), st(n), cc(n);
+  std::vector<int64_t> off(n);
+  for (int i = 0; i < n; i++) {
+    const int x1 = rects[4 * i], y1 = rects[4 * i + 1];
+    const int x2 = std::min(rects[4 * i + 2], L.page_w), y2 = std::min(rects[4 * i + 3], L.page_h);
+    if (x1 < 0 || y1 < 0 || rects[4 * i + 2] < 0 || rects[4 * i + 3] < 0)
+      return fail(h, CRNN_ERR_ARG, "negative rectangle coordinate");
+    hh[i] = std::max(0, y2 - y1); ww[i] = std::max(0, x2 - x1);
+    st[i] = L.page_w * L.page_ch; cc[i] = L.page_ch;
+    off[i] = ((int64_t)y1 * L.page_w + x1) * L.page_ch;
+    if (hh[i] == 0) return fail(h, CRNN_ERR_ZERO_H, "rectangle height 0 (ZeroDivisionError in resizeNormalize)");
+    if (resized_width(ww[i], hh[i], 32) <= 0)
+      return fail(h, CRNN_ERR_ZERO_W, "resized width 0 (height and width must be > 0)");
+  }
+  return predict_core(h, nullptr, hh.data(), ww.data(), st.data(), cc.data(), off.data(), n, pad_mode, tmax, out_raw,
+                      out_lab, out_len, out_t, out_logits);
 }
 
 int crnn_set_page(crnn_handle* h, const uint8_t* page, int32_t height, int32_t width, int32_t row_stride,
@@ -927,23 +978,9 @@ int crnn_set_page(crnn_handle* h, const uint8_t* page, int32_t height, int32_t w
   std::lock_guard<std::mutex> lk(h->mu);
   tl_cur = &h->lanes[0];
   std::lock_guard<std::mutex> lane_lk(h->lanes[0].mu);
-  if (!page || height <= 0 || width <= 0) return fail(h, CRNN_ERR_ARG, "empty page");
-  if (channels != 1 && channels != 3) return fail(h, CRNN_ERR_ARG, "channels must be 1 (gray) or 3 (BGR)");
-  if (row_stride < width * channels) return fail(h, CRNN_ERR_ARG, "row stride smaller than a row");
   int rc = ensure_device(h, false);
   if (rc) return rc;
-  const size_t rowb = (size_t)width * channels, bytes = rowb * height;
-  // any lane may still be reading the previous page
-  for (int i = 0; i < h->nlanes; i++) HIPCHK(h, hipStreamSynchronize(h->lanes[i].stream));
-  if ((rc = ensure_buf(h, h->page, bytes + 256))) return rc;
-  if ((rc = ensure_host(h, tl_cur->stage, bytes))) return rc;
-  uint8_t* st = (uint8_t*)tl_cur->stage.p;
-  if ((size_t)row_stride == rowb) memcpy(st, page, bytes);
-  else for (int y = 0; y < height; y++) memcpy(st + (size_t)y * rowb, page + (size_t)y * row_stride, rowb);
-  HIPCHK(h, hipMemcpyAsync(h->page.p, st, bytes, hipMemcpyHostToDevice, tl_cur->stream));
-  HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
-  h->page_h = height; h->page_w = width; h->page_ch = channels;
-  return 0;
+  return upload_page(h, page, height, width, row_stride, channels);
 }
 
 int crnn_predict_rects(crnn_handle* h, const int32_t* rects, int32_t n, int32_t pad_mode, int32_t tmax,
@@ -954,25 +991,20 @@ int crnn_predict_rects(crnn_handle* h, const int32_t* rects, int32_t n, int32_t 
   std::lock_guard<std::mutex> lane_lk(h->lanes[0].mu);
   if (n <= 0 || !rects || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
   if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
-  if (!h->page.p || h->page_h <= 0) return fail(h, CRNN_ERR_STATE, "no page: call crnn_set_page first");
-  // im0[y1:y2, x1:x2] (vat_detect.py:318): ends are clipped to the page like a numpy slice; negative
-  // coordinates (which numpy would wrap) are refused
-  std::vector<int32_t> hh(n), ww(n), st(n), cc(n);
-  std::vector<int64_t> off(n);
-  for (int i = 0; i < n; i++) {
-    const int x1 = rects[4 * i], y1 = rects[4 * i + 1];
-    const int x2 = std::min(rects[4 * i + 2], h->page_w), y2 = std::min(rects[4 * i + 3], h->page_h);
-    if (x1 < 0 || y1 < 0 || rects[4 * i + 2] < 0 || rects[4 * i + 3] < 0)
-      return fail(h, CRNN_ERR_ARG, "negative rectangle coordinate");
-    hh[i] = std::max(0, y2 - y1); ww[i] = std::max(0, x2 - x1);
-    st[i] = h->page_w * h->page_ch; cc[i] = h->page_ch;
-    off[i] = ((int64_t)y1 * h->page_w + x1) * h->page_ch;
-    if (hh[i] == 0) return fail(h, CRNN_ERR_ZERO_H, "rectangle height 0 (ZeroDivisionError in resizeNormalize)");
-    if (resized_width(ww[i], hh[i], 32) <= 0)
-      return fail(h, CRNN_ERR_ZERO_W, "resized width 0 (height and width must be > 0)");
-  }
-  return predict_core(h, nullptr, hh.data(), ww.data(), st.data(), cc.data(), off.data(), n, pad_mode, tmax, out_raw,
-                      out_lab, out_len, out_t, out_logits);
+  return rects_core(h, rects, n, pad_mode, tmax, out_raw, out_lab, out_len, out_t, out_logits);
+}
+
+int crnn_predict_page(crnn_handle* h, const uint8_t* page, int32_t height, int32_t width, int32_t row_stride,
+                      int32_t channels, const int32_t* rects, int32_t n, int32_t pad_mode, int32_t tmax,
+                      int32_t* out_raw, int32_t* out_lab, int32_t* out_len, int32_t* out_t, float* out_logits) {
+  if (!h) return CRNN_ERR_ARG;
+  if (n <= 0 || !rects || !out_lab || !out_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
+  if (pad_mode != CRNN_PAD_PER_LINE && pad_mode != CRNN_PAD_REFERENCE) return fail(h, CRNN_ERR_ARG, "bad pad_mode");
+  int rc;
+  std::unique_lock<std::mutex> lane_lk;
+  if ((rc = pick_lane(h, lane_lk))) return rc;
+  if ((rc = upload_page(h, page, height, width, row_stride, channels))) return rc;
+  return rects_core(h, rects, n, pad_mode, tmax, out_raw, out_lab, out_len, out_t, out_logits);
 }
 
 int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_t w, const int32_t* widths,
@@ -1113,12 +1145,12 @@ void crnn_destroy(crnn_handle* h) {
     }
     (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->db_lin_w); (void)hipFree(h->d_zero_bias);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino[i]);
-    (void)hipFree(h->page.p);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }
     for (int l = 0; l < h->nlanes; l++) {
       Lane& L = h->lanes[l];
       (void)hipFree(L.arena.p); (void)hipFree(L.pre.p); (void)hipFree(L.io.p); (void)hipHostFree(L.stage.p);
+      (void)hipFree(L.page.p);
       for (int i = 0; i < 5; i++) (void)hipEventDestroy(L.ev[i]);
       for (int i = 0; i <= MAXK; i++) (void)hipEventDestroy(L.kev[i]);
       (void)hipStreamDestroy(L.stream);

@@ -72,8 +72,7 @@ class CrnnOcrContext(object):
         if not good:
             return results
         try:
-            self.crnn.set_page(a)
-            texts = self.crnn.predict_rects([boxes[i] for i in good], max_batch=self.max_batch)
+            texts = self.crnn.ocr_page(a, [boxes[i] for i in good], max_batch=self.max_batch)
             for i, t in zip(good, texts):
                 results[i] = t
         except Exception:

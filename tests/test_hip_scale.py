@@ -204,3 +204,30 @@ def test_first_call_on_a_fresh_thread_and_handle(synth_en):
     t = threading.Thread(target=other)
     t.start(); t.join()
     assert res["stream"] and res["text"] == m.predict_lines([np.full((32, 100), 200, np.uint8)])
+
+
+@pytest.mark.gpu
+def test_pages_from_two_threads_use_their_own_lanes(golden, zh3):
+    """crnn_predict_page: concurrent callers with DIFFERENT pages (two request threads of a worker) each get a
+    lane with its own page buffer; results equal the host-cut crops."""
+    rs = np.random.RandomState(21)
+    pages = [rs.randint(0, 256, size=(400, 700, 3)).astype(np.uint8) for _ in range(2)]
+    rects = [(10, 20, 310, 60), (5, 100, 650, 140), (300, 200, 460, 236), (0, 300, 700, 399), (600, 10, 640, 50)]
+    want = [[zh3.ocr(pg[y1:y2, x1:x2]) for x1, y1, x2, y2 in rects] for pg in pages]
+    got = [None, None]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(4):
+                got[k] = zh3.ocr_page(pages[k], rects)
+                assert got[k] == want[k]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert got == want

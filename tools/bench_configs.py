@@ -87,6 +87,16 @@ def main():
     t0 = time.perf_counter()
     nt = sum(len(zh.ocr_page(pg, rr)) for pg, rr in zip(pages, rects))
     el = time.perf_counter() - t0
+    # the same pages from two threads (the two request threads of a gunicorn worker): each call takes a
+    # lane of its own, so two pages are on the device at once
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as ex:
+        list(ex.map(lambda a: zh.ocr_page(*a), list(zip(pages, rects))[:4]))
+        t0 = time.perf_counter()
+        n2 = sum(len(x) for x in ex.map(lambda a: zh.ocr_page(*a), zip(pages, rects)))
+        el2 = time.perf_counter() - t0
+    out["config5_page_rects_2_threads"] = {"pages_per_s": round(npages / el2, 1), "crops_per_s": round(n2 / el2, 1),
+                                           "seconds": round(el2, 3)}
     out["config5_page_rects"] = {"pages": npages, "crops_per_page": per_page, "pages_per_s": round(npages / el, 1),
                                  "crops_per_s": round(nt / el, 1), "seconds": round(el, 3),
                                  "note": "synthetic 1654x2339 BGR pages, 48 rectangles of the invoice crop sizes each; "
