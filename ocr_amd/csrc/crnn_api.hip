@@ -53,6 +53,8 @@ struct Lane {
   DevBuf io;         // per-call small buffers (outputs of the host path)
   DevBuf stage;      // PINNED HOST memory: packed sources on their way to the device
   std::mutex mu;     // held by whichever call is using this lane's stream and buffers
+  bool split_used = false;   // the last run_network on this lane used the hidden-split recurrence
+  DevBuf sync;       // arrival counters + time-out word of the hidden-split recurrence
   DevBuf page;       // resident page of this lane (crnn_set_page uses lane 0, crnn_predict_page any free lane)
   int page_h = 0, page_w = 0, page_ch = 0;
   float* st[11] = {};          // where the stages of the last run live (crnn_debug_stage)
@@ -73,6 +75,9 @@ struct crnn_handle {
   // Winograd F(2x2,3x3) weights U[16][Cout][Cin] for the layers in wino_mask (fp32 path only)
   std::vector<float> h_wino[7];
   unsigned wino_mask = 0;
+  // recurrence: batches of up to split_max lines use the hidden-split latency kernel in the synchronous host
+  // paths (CRNN_LSTM_SPLIT=<max lines>, 0 = never)
+  int split_max = 64;
   bool wino_fused = true;   // GEMM + output transform in one kernel (CRNN_WINO_FUSED=0: separate kernels)
   // bf16 copies (precision == CRNN_BF16): conv1..6, W_ih, embeddings / linear, packed W_hh
   std::vector<uint16_t> hb_conv_w[7], hb_wih[2], hb_whhp[2], hb_emb_w[2], hb_lin_w;
@@ -188,6 +193,7 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       L.nk = 0;
       L.arena = DevBuf(); L.pre = DevBuf(); L.io = DevBuf(); L.stage = DevBuf();
       L.page = DevBuf(); L.page_h = L.page_w = L.page_ch = 0;
+      L.sync = DevBuf();
     }
   }
   if (!h->dev_ready) {
@@ -444,8 +450,9 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
 
 // Runs the network on the normalised input already in plan.x.  widths: host
 // per-line valid widths or nullptr.  Outputs (device): plan.raw plus d_lab/d_len.
+// allow_split: the caller synchronises afterwards and checks split_timed_out() (host paths only)
 int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widths, int32_t* d_lab,
-                int32_t* d_len, bool want_logits = false) {
+                int32_t* d_len, bool want_logits = false, bool allow_split = false) {
   const int n = g.n;
   const int act = h->cfg.leaky_relu ? 2 : 1;
   const int32_t *m_p0 = nullptr, *m_c1 = nullptr, *m_w2 = nullptr, *m_w3 = nullptr, *tlen = nullptr;
@@ -490,8 +497,18 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   const int M = n * g.T;
   const double recflop = 2.0 * M * 2 * 1024 * 256;
   const double recbytes = 4.0 * M * 2048 + es * ((double)M * 512 + 2 * 1024 * 256);
+  const bool split = allow_split && !b16 && h->cfg.lstm && n <= h->split_max && (double)M * 2048.0 < 2.0e9;
+  unsigned* d_sync = nullptr;
+  if (split) {
+    int rc = ensure_buf(h, tl_cur->sync, 4096);
+    if (rc) return rc;
+    d_sync = (unsigned*)tl_cur->sync.p;                       // [0..3] time-out word (+pad), [4..] counters
+    HIPCHK(h, hipMemsetAsync(d_sync, 0, 16, s));
+  }
+  tl_cur->split_used = split;
   auto rec = [&](int l, float* out) {
     if (b16) launch_lstm_rec_bf16(p.xp, h->db_whhp[l], out, tlen, n, g.T, s);
+    else if (split) launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync + 4, d_sync, s);
     else launch_lstm_rec(p.xp, h->d_whhp[l], out, tlen, n, g.T, s);
     kmark(h, l ? "lstm1_rec" : "lstm0_rec", recflop, recbytes);
   };
@@ -645,6 +662,7 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   // Winograd layers (bit i = conv i, i in 1..5): default conv3..5 (measured best); CRNN_WINOGRAD=<mask> overrides (0 = off)
   h->wino_mask = cfg->precision == CRNN_FP32 ? 0x3Eu : 0u;
   if (const char* e = getenv("CRNN_WINO_FUSED")) h->wino_fused = atoi(e) != 0;
+  if (const char* e = getenv("CRNN_LSTM_SPLIT")) h->split_max = atoi(e);
   if (const char* e = getenv("CRNN_WINOGRAD")) h->wino_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
   for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);
   *out = h;
@@ -863,7 +881,16 @@ static int predict_core(crnn_handle* h, const uint8_t* const* imgs, const int32_
   if ((rc = run_preprocess(h, imgs, heights, widths, row_strides, channels, sel, dw, Wp, p.x, rect_off))) return rc;
   std::vector<int32_t> wv(dw.begin(), dw.end());
   const bool uniform = pad_mode == CRNN_PAD_REFERENCE;
-  if ((rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len, out_logits != nullptr))) return rc;
+  if ((rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len, out_logits != nullptr, true))) return rc;
+  if (tl_cur->split_used) {
+    // the hidden-split recurrence gives up (bounded spins) if its four workgroups per group do not all become
+    // resident in time, e.g. under heavy load from other lanes: repeat with the one-workgroup kernel then
+    unsigned tmo = 0;
+    HIPCHK(h, hipMemcpyAsync(&tmo, tl_cur->sync.p, 4, hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
+    if (tmo && (rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len, out_logits != nullptr, false)))
+      return rc;
+  }
   std::vector<int32_t> lab(nT), raw(nT), len(g.n);
   HIPCHK(h, hipMemcpyAsync(lab.data(), d_lab, nT * 4, hipMemcpyDeviceToHost, tl_cur->stream));
   HIPCHK(h, hipMemcpyAsync(raw.data(), p.raw, nT * 4, hipMemcpyDeviceToHost, tl_cur->stream));
@@ -1150,7 +1177,7 @@ void crnn_destroy(crnn_handle* h) {
     for (int l = 0; l < h->nlanes; l++) {
       Lane& L = h->lanes[l];
       (void)hipFree(L.arena.p); (void)hipFree(L.pre.p); (void)hipFree(L.io.p); (void)hipHostFree(L.stage.p);
-      (void)hipFree(L.page.p);
+      (void)hipFree(L.page.p); (void)hipFree(L.sync.p);
       for (int i = 0; i < 5; i++) (void)hipEventDestroy(L.ev[i]);
       for (int i = 0; i <= MAXK; i++) (void)hipEventDestroy(L.kev[i]);
       (void)hipStreamDestroy(L.stream);

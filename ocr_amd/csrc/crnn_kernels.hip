@@ -1015,6 +1015,159 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------
+// Latency form of the recurrence for small batches (one crop per call, a page's worth of crops): the
+// kernel above runs one workgroup per (direction, 16 lines) and is bound by its T sequential steps of
+// ~21 us.  Here FOUR workgroups share a (direction, 16 lines) group: workgroup `part` owns hidden
+// units [64 part, 64 part + 64) of all four gates, wave w the 16 units [.. + 16 w, ..+16); the wave's
+// W_hh slice (4 gate tiles x 256 k = 64 KB) stays in registers for the whole launch, so a step is 256
+// MFMAs per wave (3.4 us) instead of 1024 plus 1 MiB of weight traffic.  The price is an exchange of h
+// every step, done through the output tensor itself (each step's rows are fresh addresses):
+//   * every lane stores its 4 h values write-through (sc1) to rec[line, t, dir, unit..] (the kernel's output
+//     anyway), every wave drains (s_waitcnt vmcnt(0)), the workgroup barriers, one lane adds 1 to the
+//     group's arrival counter with an agent-scope atomic;
+//   * one lane polls the counter (relaxed, agent scope, bounded) until all four parts of this step have
+//     arrived; then the other parts' 3 x 64 units of every active line are loaded with sc1 loads (L1 is
+//     bypassed; nothing here depends on which XCD a workgroup landed on) into the LDS copy of h.
+// A line that is past its own length publishes nothing; everybody keeps its old h from LDS.
+// The same packed weights, the same MFMA sequence per accumulator and the same gate math as the kernel
+// above: results are bit-identical (tests/test_hip_scale.py).  Spins are bounded: a workgroup that waits
+// too long sets *tmo and every workgroup leaves; the host then repeats the batch with the kernel above.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+
+__global__ __launch_bounds__(256) void lstm_rec_split_kernel(const float* __restrict__ xp,
+                                                             const float* __restrict__ whhp, float* rec,
+                                                             const int32_t* __restrict__ tlen, int B, int T,
+                                                             unsigned* cnt, unsigned* tmo) {
+  __shared__ __attribute__((aligned(16))) float hs[2 * LB * HS];
+  __shared__ int s_fail;
+  const int dir = blockIdx.y, grp = blockIdx.x >> 2, part = blockIdx.x & 3, b0 = grp * LB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
+  const int b = b0 + bl;
+  const int Ti = (b < B) ? (tlen ? tlen[b] : T) : 0;
+  int Tmax = 0;
+  for (int j = 0; j < LB; j++) {
+    const int bb = b0 + j;
+    const int tj = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
+    Tmax = tj > Tmax ? tj : Tmax;
+  }
+  for (int i = tid; i < 2 * LB * HS; i += 256) hs[i] = 0.f;
+  if (tid == 0) s_fail = 0;
+  // exchange loads: 3 other parts x 16 lines x 16 chunks of 4 units = 768 float4, 3 per thread
+  int xl_line[3], xl_unit[3], xl_T[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int e = i * 256 + tid;            // 0..767
+    const int op = e >> 8;                  // which of the 3 other parts
+    const int p2 = op + (op >= part ? 1 : 0);
+    xl_line[i] = (e >> 4) & 15;
+    xl_unit[i] = p2 * 64 + (e & 15) * 4;
+    const int bb = b0 + xl_line[i];
+    xl_T[i] = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
+  }
+  const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, 0x7FFFFFFF, 0x00020000);
+  gu32_t* my_cnt = (gu32_t*)(cnt + dir * (gridDim.x >> 2) + grp);
+  float c[4], h[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { c[r] = 0.f; h[r] = 0.f; }
+  // the wave's weights: gate g, its 16 units, all 16 k-groups -- 64 float4 per lane, resident
+  f32x4 w[4][16];
+  {
+    const f32x4* wp = (const f32x4*)whhp + ((size_t)(dir * 4 + part) * 16 * 16) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int kg = 0; kg < 16; kg++) w[g][kg] = wp[(size_t)((g * 4 + wave) * 16 + kg) * 64];
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int s = 0; s < Tmax; s++) {
+    const bool active = s < Ti;
+    const int t = active ? (dir ? (Ti - 1 - s) : s) : 0;
+    const size_t rowi = (size_t)(b < B ? b : 0) * T + t;
+    const float* xrow = xp + rowi * 2048 + dir * 1024 + part * 64 + wave * 16 + q * 4;
+    f32x4 xg[4], acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      xg[g] = active ? *(const f32x4*)(xrow + g * 256) : z;
+      acc[g] = z;
+    }
+    const float* hrow = hs + cur * LB * HS + bl * HS + 4 * q;
+#pragma unroll
+    for (int kg = 0; kg < 16; kg++) {
+      const f32x4 hv = *(const f32x4*)(hrow + kg * 16);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][kg][j], hv[j], acc[g], 0, 0, 0);
+    }
+    f32x4 hv4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (active) {
+        const float ig = sigmoidf_(acc[0][r] + xg[0][r]);
+        const float fg = sigmoidf_(acc[1][r] + xg[1][r]);
+        const float gg = tanhf_(acc[2][r] + xg[2][r]);
+        const float og = sigmoidf_(acc[3][r] + xg[3][r]);
+        c[r] = fg * c[r] + ig * gg;
+        h[r] = og * tanhf_(c[r]);
+      }
+      hv4[r] = h[r];
+    }
+    const int myu = part * 64 + wave * 16 + q * 4;
+    *(f32x4*)(hs + (cur ^ 1) * LB * HS + bl * HS + myu) = hv4;
+    if (active)   // write-through store: the output row AND the hand-off to the other three workgroups
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv4), rec_rsrc,
+                                             (unsigned)((rowi * 512 + dir * 256 + myu) * 4), 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = 4u * (unsigned)(s + 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22) || __hip_atomic_load((gu32_t*)tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_fail = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_fail) return;     // uniform: everybody leaves; the host repeats the batch with lstm_rec_kernel
+    // the other parts' h of this step (sc1 loads), or the old value for lines that have ended
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int Tl = xl_T[i], ln = xl_line[i];
+      const bool act = s < Tl;
+      const int tl = dir ? (Tl - 1 - s) : s;
+      float* dst = hs + (cur ^ 1) * LB * HS + ln * HS + xl_unit[i];
+      if (act) {
+        const size_t ro = ((size_t)(b0 + ln) * T + tl) * 512 + dir * 256 + xl_unit[i];
+        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (unsigned)(ro * 4), 0, 16);
+        *(f32x4*)dst = __builtin_bit_cast(f32x4, v);
+      } else {
+        *(f32x4*)dst = *(const f32x4*)(hs + cur * LB * HS + ln * HS + xl_unit[i]);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// cnt: 2 * groups counters (zeroed here), tmo: one word (zeroed here); both device memory
+void launch_lstm_rec_split(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,
+                           int T, unsigned* cnt, unsigned* tmo, hipStream_t s) {
+  const int groups = (B + LB - 1) / LB;
+  (void)hipMemsetAsync(cnt, 0, ((size_t)2 * groups * 4 + 15) / 16 * 16, s);
+  hipLaunchKernelGGL(lstm_rec_split_kernel, dim3(groups * 4, 2), dim3(256), 0, s, xp, whh_packed, rec, tlen, B, T,
+                     cnt, tmo);
+}
+
 void launch_lstm_rec(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,
                      int T, hipStream_t s) {
   hipLaunchKernelGGL(lstm_rec_kernel, dim3((B + LB - 1) / LB, 2), dim3(256), 0, s, xp, whh_packed, rec,

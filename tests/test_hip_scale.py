@@ -231,3 +231,37 @@ def test_pages_from_two_threads_use_their_own_lanes(golden, zh3):
         t.join()
     assert not errs, errs
     assert got == want
+
+
+@pytest.mark.gpu
+def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh):
+    """Small batches use the four-workgroups-per-group recurrence (lstm_rec_split_kernel) in the synchronous
+    host paths; it must reproduce the one-workgroup kernel bit for bit: same logits for n = 1, 17 and 48 lines
+    of different widths (lines ending at different steps exercise the keep-old-h path of the exchange)."""
+    from ocr_amd.crnn.network_hip import CRNN
+    G, M = golden
+    old = os.environ.get("CRNN_LSTM_SPLIT")
+    try:
+        os.environ["CRNN_LSTM_SPLIT"] = "0"
+        ref = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1)
+        ref.load_state_dict(synth_zh)
+        os.environ["CRNN_LSTM_SPLIT"] = "64"
+        spl = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1)
+        spl.load_state_dict(synth_zh)
+    finally:
+        if old is None:
+            os.environ.pop("CRNN_LSTM_SPLIT", None)
+        else:
+            os.environ["CRNN_LSTM_SPLIT"] = old
+    rs = np.random.RandomState(5)
+    inv = [G[k] for k in sorted(G.files) if k.startswith("inv/") and k.endswith("/bgr")]
+    pool = inv + [rs.randint(0, 256, size=(32, int(w))).astype(np.uint8) for w in rs.randint(8, 700, size=40)]
+    for n in (1, 17, 48):
+        lines = [pool[i % len(pool)] for i in range(n)]
+        a = ref.forward_logits(lines)
+        b = spl.forward_logits(lines)
+        assert np.array_equal(a[1], b[1])                 # T per line
+        assert np.array_equal(a[0], b[0])                 # raw arg-max
+        for i in range(n):
+            assert np.array_equal(a[2][i, :a[1][i]], b[2][i, :b[1][i]]), (n, i)
+        assert ref.predict_lines(lines) == spl.predict_lines(lines)

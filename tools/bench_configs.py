@@ -71,6 +71,18 @@ def main():
                                           "predict_lines (H2D + gray + resize included); detectors absent, no pages/s"}
     assert len(texts) == ncrops
 
+    # ---------------- the reference's own call pattern: ocr_predict(crop), one crop at a time (ocr_context.py:119)
+    one = [crops[i] for i in range(64)]
+    for c in one[:8]:
+        zh.ocr(c)
+    t0 = time.perf_counter()
+    for c in one:
+        zh.ocr(c)
+    el1 = time.perf_counter() - t0
+    out["single_crop_calls"] = {"crops": len(one), "ms_per_call": round(el1 / len(one) * 1e3, 3),
+                                "crops_per_s": round(len(one) / el1, 1),
+                                "note": "CRNN.ocr(bgr) one crop per call, synchronous: bound by the T sequential recurrence steps"}
+
     # ---------------- config 5, page form: one upload per page, crops as rectangles
     npages, per_page = 24, 48
     ph, pw = 2339, 1654                       # A4 at 200 dpi
