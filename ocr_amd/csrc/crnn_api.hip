@@ -75,9 +75,13 @@ struct crnn_handle {
   // Winograd F(2x2,3x3) weights U[16][Cout][Cin] for the layers in wino_mask (fp32 path only)
   std::vector<float> h_wino[7];
   unsigned wino_mask = 0;
-  // recurrence: batches of up to split_max lines use the hidden-split latency kernel in the synchronous host
-  // paths (CRNN_LSTM_SPLIT=<max lines>, 0 = never)
-  int split_max = 64;
+  // recurrence: batches of up to split_max lines (8 workgroups per 16 lines: 192 of the 256 CUs at 384) use the
+  // hidden-split latency kernel in the synchronous host paths (CRNN_LSTM_SPLIT=<max lines>, 0 = never)
+  int split_max = 384;
+  // at most one hidden-split kernel runs at a time (each waits for the previous one's event): two of them, each
+  // partly resident and spinning for workgroups that cannot be placed, would only end by their time-outs
+  std::mutex split_mu;
+  hipEvent_t split_ev = nullptr;
   bool wino_fused = true;   // GEMM + output transform in one kernel (CRNN_WINO_FUSED=0: separate kernels)
   // bf16 copies (precision == CRNN_BF16): conv1..6, W_ih, embeddings / linear, packed W_hh
   std::vector<uint16_t> hb_conv_w[7], hb_wih[2], hb_whhp[2], hb_emb_w[2], hb_lin_w;
@@ -188,6 +192,7 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     // belong to its context -- drop them, do not free)
     h->dev_ready = false;
     h->weights_on_dev = false;
+    h->split_ev = nullptr;
     for (Lane& L : h->lanes) {
       L.ev_valid = false;
       L.nk = 0;
@@ -508,7 +513,13 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   tl_cur->split_used = split;
   auto rec = [&](int l, float* out) {
     if (b16) launch_lstm_rec_bf16(p.xp, h->db_whhp[l], out, tlen, n, g.T, s);
-    else if (split) launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync + 4, d_sync, s);
+    else if (split) {
+      std::lock_guard<std::mutex> lk(h->split_mu);
+      if (!h->split_ev) (void)hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming);
+      if (h->split_ev) (void)hipStreamWaitEvent(s, h->split_ev, 0);
+      launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync + 4, d_sync, s);
+      if (h->split_ev) (void)hipEventRecord(h->split_ev, s);
+    }
     else launch_lstm_rec(p.xp, h->d_whhp[l], out, tlen, n, g.T, s);
     kmark(h, l ? "lstm1_rec" : "lstm0_rec", recflop, recbytes);
   };

@@ -236,7 +236,7 @@ def test_pages_from_two_threads_use_their_own_lanes(golden, zh3):
 @pytest.mark.gpu
 def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh):
     """Small batches use the four-workgroups-per-group recurrence (lstm_rec_split_kernel) in the synchronous
-    host paths; it must reproduce the one-workgroup kernel bit for bit: same logits for n = 1, 17 and 48 lines
+    host paths; it must reproduce the one-workgroup kernel bit for bit: same logits for n = 1, 17, 48 and 200 lines
     of different widths (lines ending at different steps exercise the keep-old-h path of the exchange)."""
     from ocr_amd.crnn.network_hip import CRNN
     G, M = golden
@@ -245,7 +245,7 @@ def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh):
         os.environ["CRNN_LSTM_SPLIT"] = "0"
         ref = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1)
         ref.load_state_dict(synth_zh)
-        os.environ["CRNN_LSTM_SPLIT"] = "64"
+        os.environ["CRNN_LSTM_SPLIT"] = "384"
         spl = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1)
         spl.load_state_dict(synth_zh)
     finally:
@@ -256,7 +256,7 @@ def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh):
     rs = np.random.RandomState(5)
     inv = [G[k] for k in sorted(G.files) if k.startswith("inv/") and k.endswith("/bgr")]
     pool = inv + [rs.randint(0, 256, size=(32, int(w))).astype(np.uint8) for w in rs.randint(8, 700, size=40)]
-    for n in (1, 17, 48):
+    for n in (1, 17, 48, 200):
         lines = [pool[i % len(pool)] for i in range(n)]
         a = ref.forward_logits(lines)
         b = spl.forward_logits(lines)
@@ -265,3 +265,32 @@ def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh):
         for i in range(n):
             assert np.array_equal(a[2][i, :a[1][i]], b[2][i, :b[1][i]]), (n, i)
         assert ref.predict_lines(lines) == spl.predict_lines(lines)
+
+
+@pytest.mark.gpu
+def test_split_recurrences_of_concurrent_callers(golden, synth_en):
+    """Three threads, each with batches that use the hidden-split recurrence, on one handle with three lanes:
+    the split kernels are chained (one on the device at a time), results equal the single-threaded ones."""
+    from ocr_amd.crnn.network_hip import CRNN
+    m = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish, device=0, lanes=3)
+    m.load_state_dict(synth_en)
+    rs = np.random.RandomState(9)
+    jobs = [[rs.randint(0, 256, size=(32, int(w))).astype(np.uint8) for w in rs.randint(40, 400, size=n)]
+            for n in (5, 40, 90)]
+    want = [m.predict_lines(j, min_cols=1 << 30) for j in jobs]
+    got = [None] * 3
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(6):
+                got[k] = m.predict_lines(jobs[k], min_cols=1 << 30)
+                assert got[k] == want[k]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
