@@ -1185,6 +1185,7 @@ void crnn_destroy(crnn_handle* h) {
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }
+    if (h->split_ev) (void)hipEventDestroy(h->split_ev);
     for (int l = 0; l < h->nlanes; l++) {
       Lane& L = h->lanes[l];
       (void)hipFree(L.arena.p); (void)hipFree(L.pre.p); (void)hipFree(L.io.p); (void)hipHostFree(L.stage.p);
