@@ -718,6 +718,9 @@ void launch_wino_gemm(const WinoGemm& p, hipStream_t s) {
   const double peak[4] = {0, 1.0, 0, 0.94};
   int shape = 1;
   double best = 0;
+  // less than one round of 128x64 blocks: latency-bound, and the 64x64 shape halves the MFMA chain per wave
+  // and per K step (n = 1: conv1-5 0.71 -> 0.40 ms; equal or better up to ~96 lines)
+  if (units[1] <= 512) { launch_wino_shape(p, 3, 0, p.ntile, s); return; }
   for (int k = 1; k <= 3; k += 2) {
     const double fill = (double)units[k] / ((double)((units[k] + slots[k] - 1) / slots[k]) * slots[k]);
     const double est = peak[k] * (1.0 - (1.0 - fill) / 3.0);
