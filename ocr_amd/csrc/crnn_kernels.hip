@@ -1305,22 +1305,36 @@ __device__ __forceinline__ int clip8(int v) {
   return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
+// One thread makes 4 consecutive bytes of the job's intermediate image (rows are contiguous, so the
+// flattened pixel index runs over rows; no idle lanes at row ends, one 4-byte store per thread).
 __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict__ src,
                                                        const ResizeJob* __restrict__ jobs,
                                                        const int32_t* __restrict__ coef,
                                                        uint8_t* __restrict__ tmp) {
   const ResizeJob j = jobs[blockIdx.z];
-  const int yy = blockIdx.y;
-  const int xx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (yy >= j.th || xx >= j.dw) return;
+  const int npix = j.th * j.dw;
+  const int p0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (p0 >= npix) return;
   const int32_t* bh = coef + j.coef_off;
   const int32_t* kh = bh + 2 * j.dw;
-  const int xmin = bh[2 * xx], xmax = bh[2 * xx + 1];
-  const int32_t* k = kh + (long)xx * j.ksh;
-  const uint8_t* row = src + j.src_off + (long)(yy + j.ybox_first) * j.stride;
-  int ss = 1 << (PREC - 1);
-  for (int x = 0; x < xmax; x++) ss += src_gray(row, x + xmin, j.ch) * k[x];
-  tmp[j.tmp_off + (long)yy * j.dw + xx] = (uint8_t)clip8(ss);
+  unsigned packed = 0;
+  int yy = p0 / j.dw, xx = p0 - yy * j.dw;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    if (p0 + e < npix) {
+      const int xmin = bh[2 * xx], xmax = bh[2 * xx + 1];
+      const int32_t* k = kh + (long)xx * j.ksh;
+      const uint8_t* row = src + j.src_off + (long)(yy + j.ybox_first) * j.stride;
+      int ss = 1 << (PREC - 1);
+      for (int x = 0; x < xmax; x++) ss += src_gray(row, x + xmin, j.ch) * k[x];
+      packed |= (unsigned)clip8(ss) << (8 * e);
+    }
+    xx++;
+    if (xx == j.dw) { xx = 0; yy++; }
+  }
+  uint8_t* o = tmp + j.tmp_off + p0;        // tmp_off is 16-byte aligned, p0 a multiple of 4
+  if (p0 + 3 < npix) *(unsigned*)o = packed;
+  else for (int e = 0; p0 + e < npix; e++) o[e] = (uint8_t)(packed >> (8 * e));
 }
 
 __global__ __launch_bounds__(256) void resize_v_kernel(const ResizeJob* __restrict__ jobs,
@@ -1347,7 +1361,8 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const ResizeJob* __restri
 
 void launch_resize_h(const uint8_t* src, const ResizeJob* jobs, const int32_t* coef, uint8_t* tmp, int n,
                      int max_th, int max_dw, hipStream_t s) {
-  hipLaunchKernelGGL(resize_h_kernel, dim3((max_dw + 255) / 256, max_th, n), dim3(256), 0, s, src, jobs,
+  const long maxpix = (long)max_th * max_dw;
+  hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)((maxpix + 1023) / 1024), 1, n), dim3(256), 0, s, src, jobs,
                      coef, tmp);
 }
 void launch_resize_v(const uint8_t* /*src*/, const ResizeJob* jobs, const int32_t* coef,
