@@ -640,7 +640,9 @@ int run_preprocess(crnn_handle* h, const uint8_t* const* imgs, const int32_t* he
   if (h->kprof) HIPCHK(h, hipEventRecord(tl_cur->kev[0], s));
   double src_px = 0, tmp_px = 0;   // algorithmic bytes: sources read, intermediate written + read, f32 written
   for (const ResizeJob& J : jobs) { src_px += (double)J.sh * J.sw * J.ch; tmp_px += (double)J.th * J.dw; }
-  launch_resize_h(d_src, d_jobs, d_coef, d_tmp, nb, max_th, max_dw, s);
+  int max_sw = 1;
+  for (const ResizeJob& J : jobs) max_sw = std::max(max_sw, (int)J.sw);
+  launch_resize_h(d_src, d_jobs, d_coef, d_tmp, nb, max_th, max_dw, max_sw, s);
   kmark(h, "resize_h", 0, src_px + tmp_px);
   launch_resize_v(d_src, d_jobs, d_coef, d_tmp, d_x, nb, Wp, s);
   kmark(h, "resize_v", 0, tmp_px + 4.0 * nb * 32 * Wp);

@@ -216,7 +216,7 @@ struct ResizeJob {        // one source image (device resident)
 };
 // gray + Pillow BILINEAR horizontal pass -> tmp u8
 void launch_resize_h(const uint8_t* src, const ResizeJob* jobs, const int32_t* coef, uint8_t* tmp,
-                     int n, int max_th, int max_dw, hipStream_t s);
+                     int n, int max_th, int max_dw, int max_sw, hipStream_t s);
 // vertical pass + normalise -> f32 [n,32,Wp] (zero beyond dw)
 void launch_resize_v(const uint8_t* src, const ResizeJob* jobs, const int32_t* coef, const uint8_t* tmp,
                      float* out, int n, int Wp, hipStream_t s);

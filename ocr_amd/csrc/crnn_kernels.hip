@@ -1337,6 +1337,40 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict
   else for (int e = 0; p0 + e < npix; e++) o[e] = (uint8_t)(packed >> (8 * e));
 }
 
+// Row-staged form: a block owns RH_ROWS source rows of one job; it converts each source pixel to gray ONCE
+// into LDS (coalesced reads of the source row; the per-output-pixel form above converts every source
+// pixel 2-3 times, once per overlapping window) and then resamples from LDS.  Sources wider than
+// RH_MAXW fall back to the kernel above.  Same integer arithmetic, bit for bit.
+constexpr int RH_ROWS = 4, RH_MAXW = 4096;
+
+__global__ __launch_bounds__(256) void resize_h_rows_kernel(const uint8_t* __restrict__ src,
+                                                            const ResizeJob* __restrict__ jobs,
+                                                            const int32_t* __restrict__ coef,
+                                                            uint8_t* __restrict__ tmp) {
+  __shared__ uint8_t gray[RH_ROWS][RH_MAXW];
+  const ResizeJob j = jobs[blockIdx.z];
+  const int r0 = blockIdx.x * RH_ROWS;
+  if (r0 >= j.th) return;
+  const int nr = min(RH_ROWS, j.th - r0);
+  for (int r = 0; r < nr; r++) {
+    const uint8_t* row = src + j.src_off + (long)(r0 + r + j.ybox_first) * j.stride;
+    for (int x = threadIdx.x; x < j.sw; x += 256) gray[r][x] = (uint8_t)src_gray(row, x, j.ch);
+  }
+  __syncthreads();
+  const int32_t* bh = coef + j.coef_off;
+  const int32_t* kh = bh + 2 * j.dw;
+  const int npix = nr * j.dw;
+  uint8_t* o = tmp + j.tmp_off + (long)r0 * j.dw;
+  for (int p = threadIdx.x; p < npix; p += 256) {
+    const int r = p / j.dw, xx = p - r * j.dw;
+    const int xmin = bh[2 * xx], xmax = bh[2 * xx + 1];
+    const int32_t* k = kh + (long)xx * j.ksh;
+    int ss = 1 << (PREC - 1);
+    for (int x = 0; x < xmax; x++) ss += (int)gray[r][x + xmin] * k[x];
+    o[p] = (uint8_t)clip8(ss);
+  }
+}
+
 __global__ __launch_bounds__(256) void resize_v_kernel(const ResizeJob* __restrict__ jobs,
                                                        const int32_t* __restrict__ coef,
                                                        const uint8_t* __restrict__ tmp,
@@ -1360,7 +1394,12 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const ResizeJob* __restri
 }
 
 void launch_resize_h(const uint8_t* src, const ResizeJob* jobs, const int32_t* coef, uint8_t* tmp, int n,
-                     int max_th, int max_dw, hipStream_t s) {
+                     int max_th, int max_dw, int max_sw, hipStream_t s) {
+  if (max_sw <= RH_MAXW) {
+    hipLaunchKernelGGL(resize_h_rows_kernel, dim3((max_th + RH_ROWS - 1) / RH_ROWS, 1, n), dim3(256), 0, s, src, jobs,
+                       coef, tmp);
+    return;
+  }
   const long maxpix = (long)max_th * max_dw;
   hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)((maxpix + 1023) / 1024), 1, n), dim3(256), 0, s, src, jobs,
                      coef, tmp);

@@ -53,7 +53,8 @@ def test_preprocess_bit_exact(golden, hip_zh):
     assert np.array_equal(g, O.resize_normalize(O.bgr_to_gray(crop)))
 
 
-@pytest.mark.parametrize("shape", [(7, 50), (32, 280), (100, 33), (61, 999), (33, 64), (300, 900), (31, 31)])
+@pytest.mark.parametrize("shape", [(7, 50), (32, 280), (100, 33), (61, 999), (33, 64), (300, 900), (31, 31), (64, 4096),
+                                   (70, 4100), (33, 5000)])   # the last two: wider than the row-staged kernel takes
 def test_preprocess_random_sizes(shape, hip_zh):
     from oracle import oracle as O
     rs = np.random.RandomState(shape[0] * 1000 + shape[1])
