@@ -203,13 +203,14 @@ def main():
     peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     lines_total = BATCH * args.steps * world
     value = lines_total / elapsed
-    gemm_names = [n for n in order if (n.startswith("conv") and n != "conv0_pool0" and not n.endswith(("_win", "_wout")))
+    gemm_names = [n for n in order if (n.startswith("conv") and n != "conv0_pool0" and not n.endswith(("_win", "_wout", "_win4", "_wout4")))
                   or n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
     # two GEMM kernels on the fp32 path: layers with a "<layer>_win" launch run through the fused
     # Winograd kernel (wino_gemm_kernel), the rest through conv_gemm_kernel.  The roofline object is
     # for whichever takes more of the step (rocprof's per-kernel average is over the same launches).
     wino_names = [n for n in gemm_names if (n.split("_")[0] + "_win") in order]
-    direct_names = [n for n in gemm_names if n not in wino_names]
+    wino4_names = [n for n in gemm_names if n.endswith("_f4")]
+    direct_names = [n for n in gemm_names if n not in wino_names and n not in wino4_names]
     direct_kernel = "conv_gemm_kernel" if args.precision == "fp32" else "conv_gemm_bf16_kernel"
 
     def family(kernel, names, what):
@@ -226,6 +227,10 @@ def main():
         fams.append(family("wino_gemm_dma_kernel", wino_names,
                            "Winograd F(2x2,3x3) GEMM + output transform, executed MFMA FLOPs; a launch here is one layer = "
                            "the 128x128-tile launch over the full rounds plus the small-tile launch over the remaining tiles"))
+    if wino4_names:
+        fams.append(family("wino4_gemm_kernel", wino4_names,
+                           "Winograd F(4x4,3x3): the 36 component GEMMs of a layer as one persistent launch of 128x128 "
+                           "units, executed MFMA FLOPs"))
     fams.append(family(direct_kernel, direct_names, "implicit-GEMM conv + LSTM input projections + embedding + classifier"))
     fams.sort(key=lambda f: -f["ms_per_step"])
     dom = fams[0]

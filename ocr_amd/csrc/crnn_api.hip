@@ -75,6 +75,11 @@ struct crnn_handle {
   // Winograd F(2x2,3x3) weights U[16][Cout][Cin] for the layers in wino_mask (fp32 path only)
   std::vector<float> h_wino[7];
   unsigned wino_mask = 0;
+  // Winograd F(4x4,3x3) weights U[36][Cout][Cin] for the layers in wino4_mask (they take precedence over
+  // wino_mask for batches of at least wino4_min_n lines; measured faster from one line up, so the default is 1)
+  std::vector<float> h_wino4[7];
+  unsigned wino4_mask = 0;
+  int wino4_min_n = 1;
   // recurrence: batches of up to split_max lines (8 workgroups per 16 lines: 192 of the 256 CUs at 384) use the
   // hidden-split latency kernel in the synchronous host paths (CRNN_LSTM_SPLIT=<max lines>, 0 = never)
   int split_max = 384;
@@ -100,6 +105,7 @@ struct crnn_handle {
   float* d_lin_w = nullptr;
   float* d_lin_b = nullptr;
   float* d_wino[7] = {};
+  float* d_wino4[7] = {};
   float* d_zero_bias = nullptr;   // 512 zeros: the Winograd GEMMs add the bias in the output transform
   uint16_t* db_conv_w[7] = {};
   uint16_t* db_wih[2] = {};
@@ -242,6 +248,8 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       if ((rc = upload16(h, h->hb_conv_w[i], &h->db_conv_w[i]))) return rc;
     for (int i = 0; i < 7; i++)
       if ((rc = upload(h, h->h_wino[i], &h->d_wino[i]))) return rc;
+    for (int i = 0; i < 7; i++)
+      if ((rc = upload(h, h->h_wino4[i], &h->d_wino4[i]))) return rc;
     for (int l = 0; l < 2; l++) {
       if ((rc = upload16(h, h->hb_wih[l], &h->db_wih[l]))) return rc;
       if ((rc = upload16(h, h->hb_whhp[l], &h->db_whhp[l]))) return rc;
@@ -324,6 +332,8 @@ struct Plan {
   size_t bytes;
 };
 
+static bool use_wino4(const crnn_handle* h, int n) { return h->wino4_mask && n >= h->wino4_min_n; }
+
 Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
   Plan p{};
   size_t off = 0;
@@ -366,6 +376,15 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
         vmax = std::max(vmax, 16 * tl[i] * NM[i - 1]);
         if (!h->wino_fused) mmax = std::max(mmax, 16 * tl[i] * NM[i]);
       }
+    if (use_wino4(h, (int)n)) {
+      const int hh[6] = {0, 16, 8, 8, 4, 4}, ww[6] = {0, g.W1, g.W2, g.W2, g.W3, g.W3};
+      for (int i = 1; i <= 5; i++)
+        if ((h->wino4_mask >> i) & 1u) {
+          const size_t tp = (size_t)wino4_pad(wino4_tiles((int)n, hh[i], ww[i]));
+          vmax = std::max(vmax, 36 * tp * NM[i - 1]);
+          mmax = std::max(mmax, 36 * tp * NM[i]);
+        }
+    }
     p.wv = take(vmax);
     p.wm = take(mmax);
   }
@@ -405,6 +424,26 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
           int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr, float* pool_out = nullptr) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   const bool b16 = h->cfg.precision == CRNN_BF16;
+  if (!b16 && ((h->wino4_mask >> layer) & 1u) && wino_v && wino_m && use_wino4(h, n)) {
+    // Winograd F(4x4,3x3): input transform, 36 GEMMs (K = Cin) in one persistent launch, output transform
+    static const char* wn4[3][7] = {{"", "conv1_win4", "conv2_win4", "conv3_win4", "conv4_win4", "conv5_win4", ""},
+                                    {"", "conv1_f4", "conv2_f4", "conv3_f4", "conv4_f4", "conv5_f4", ""},
+                                    {"", "conv1_wout4", "conv2_wout4", "conv3_wout4", "conv4_wout4", "conv5_wout4", ""}};
+    const int Co = NM[layer];
+    const long tiles = wino4_tiles(n, Hin, Win), tp = wino4_pad(tiles);
+    hipStream_t s = tl_cur->stream;
+    launch_wino4_in((const float*)A, wino_v, n, Hin, Win, Cin, s);
+    kmark(h, wn4[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 36.0 * tiles * Cin));
+    Wino4Gemm w{};
+    w.V = wino_v; w.U = h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co; w.Cin = Cin;
+    launch_wino4_gemm(w, s);
+    kmark(h, wn4[1][layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * 36 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
+    launch_wino4_out(wino_m, h->d_conv_b[layer], pool_out ? pool_out : (float*)C, wvalid, n, Hin, Win, Co,
+                     h->cfg.leaky_relu ? 2 : 1, pool_out ? 1 : 0, s);
+    kmark(h, wn4[2][layer], 0,
+          4.0 * (36.0 * tiles * Co + (pool_out ? (double)n * (Hin / 2) * (Win / 2) : (double)n * Hin * Win) * Co));
+    return pool_out != nullptr;
+  }
   if (!b16 && ((h->wino_mask >> layer) & 1u) && wino_v) {
     // Winograd F(2x2,3x3): input transform, 16 batched GEMMs (K = Cin), output transform
     static const char* wn[3][7] = {{"", "conv1_win", "conv2_win", "conv3_win", "conv4_win", "conv5_win", ""},
@@ -681,6 +720,11 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   // Winograd layers (bit i = conv i, i in 1..5): default conv3..5 (measured best); CRNN_WINOGRAD=<mask> overrides (0 = off)
   h->wino_mask = cfg->precision == CRNN_FP32 ? 0x3Eu : 0u;
   if (const char* e = getenv("CRNN_WINO_FUSED")) h->wino_fused = atoi(e) != 0;
+  // F(4x4) layers (bit i = conv i): default conv2..5 (conv1, K = 64 per component, is faster as fused F(2x2)
+  // with pool1 in its epilogue); CRNN_WINOGRAD_F4=<mask> overrides (0 = off), CRNN_WINO4_MIN_N=<lines>
+  h->wino4_mask = cfg->precision == CRNN_FP32 ? 0x3Cu : 0u;
+  if (const char* e = getenv("CRNN_WINOGRAD_F4")) h->wino4_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
+  if (const char* e = getenv("CRNN_WINO4_MIN_N")) h->wino4_min_n = atoi(e);
   if (const char* e = getenv("CRNN_LSTM_SPLIT")) h->split_max = atoi(e);
   if (const char* e = getenv("CRNN_WINOGRAD")) h->wino_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
   for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);
@@ -775,6 +819,36 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
         for (int a = 0; a < 4; a++)
           for (int b = 0; b < 4; b++)
             h->h_wino[i][((size_t)(a * 4 + b) * co + o) * cin + c] =
+                (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+      }
+    }
+  }
+  // F(4x4,3x3) weights: U = G g G^T, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+  for (int i = 1; i <= 5; i++) {
+    if (!((h->wino4_mask >> i) & 1u)) continue;
+    const int cin = NM[i - 1], co = NM[i];
+    const std::string pc = "cnn.conv" + std::to_string(i) + ".";
+    const float* w = m[pc + "weight"]->data;
+    const float *g = nullptr, *var = nullptr;
+    if (HAS_BN[i]) {
+      const std::string pb = "cnn.batchnorm" + std::to_string(i) + ".";
+      g = m[pb + "weight"]->data;
+      var = m[pb + "running_var"]->data;
+    }
+    static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    h->h_wino4[i].assign((size_t)36 * co * cin, 0.f);
+    for (int o = 0; o < co; o++) {
+      const double sc = g ? (double)g[o] / std::sqrt((double)var[o] + 1e-5) : 1.0;
+      for (int c = 0; c < cin; c++) {
+        double gg[3][3], t[6][3];
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) gg[a][b] = (double)w[(((size_t)o * cin + c) * 3 + a) * 3 + b] * sc;
+        for (int a = 0; a < 6; a++)
+          for (int b = 0; b < 3; b++) t[a][b] = G[a][0] * gg[0][b] + G[a][1] * gg[1][b] + G[a][2] * gg[2][b];
+        for (int a = 0; a < 6; a++)
+          for (int b = 0; b < 6; b++)
+            h->h_wino4[i][((size_t)(a * 6 + b) * co + o) * cin + c] =
                 (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
       }
     }
@@ -1191,6 +1265,7 @@ void crnn_destroy(crnn_handle* h) {
     }
     (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->db_lin_w); (void)hipFree(h->d_zero_bias);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino[i]);
+    for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }
     if (h->split_ev) (void)hipEventDestroy(h->split_ev);

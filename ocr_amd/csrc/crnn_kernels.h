@@ -161,6 +161,24 @@ struct WinoGemm {
 };
 void launch_wino_gemm(const WinoGemm& p, hipStream_t s);
 
+// Winograd F(4x4,3x3) (fp32): 36 components per 4x4 output tile, 2.25 multiplies per output and input
+// channel instead of 9 (direct) or 4 (F(2x2)).  Three kernels: input transform x -> V[36][ntile_pad][Cin],
+// 36 GEMMs V U^T -> M[36][ntile_pad][Cout] in one persistent launch, output transform (+ bias, activation,
+// width mask, optionally MaxPool 2x2/2) M -> NHWC.  H % 4 == 0; ntile_pad = tiles rounded up to 128
+// (the padding rows of V are never written and their products never read).
+struct Wino4Gemm {
+  const float* V;   // [36][ntile_pad][Cin]
+  const float* U;   // [36][N][Cin]
+  float* M;         // [36][ntile_pad][N]
+  int ntile_pad, N, Cin;
+};
+inline long wino4_tiles(int B, int H, int W) { return (long)B * (H / 4) * ((W + 3) / 4); }
+inline long wino4_pad(long tiles) { return (tiles + 127) / 128 * 128; }
+void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s);
+void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s);
+void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
+                      int Cout, int act, int pool, hipStream_t s);
+
 // conv0 (1->64, 3x3, pad 1) + ReLU + MaxPool 2x2/2, direct (K = 9, HBM-bound).
 // in f32 [B,32,W]; out NHWC [B,16,W/2,64]; w1valid: per-sample valid pooled width or nullptr.
 void launch_conv0_pool(const float* in, const float* w9x64, const float* bias, float* out,

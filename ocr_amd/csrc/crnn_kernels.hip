@@ -748,6 +748,325 @@ void launch_wino_out(const float* Mo, const float* bias, float* y, const int32_t
 }
 
 // ---------------------------------------------------------------------------
+// Winograd F(4x4,3x3), interpolation points 0, +-1, +-2, inf (fp32):
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// (G, applied to the weights on the host in double, is in crnn_api.hip.)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wino4_bt(const f32x4 (&d)[6], f32x4 (&u)[6]) {
+  const f32x4 s12 = d[1] + d[2], d12 = d[1] - d[2], s34 = d[4] + d[3], d43 = d[4] - d[3];
+  const f32x4 d42 = d[4] - d[2], d31 = d[3] - d[1];
+  u[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  u[1] = s34 - 4.f * s12;
+  u[2] = d43 + 4.f * d12;
+  u[3] = d42 + 2.f * d31;
+  u[4] = d42 - 2.f * d31;
+  u[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+__device__ __forceinline__ void wino4_at(const f32x4 (&m)[6], f32x4 (&r)[4]) {
+  const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  r[0] = m[0] + s12 + s34;
+  r[1] = d12 + 2.f * d34;
+  r[2] = s12 + 4.f * s34;
+  r[3] = d12 + 8.f * d34 + m[5];
+}
+
+// One thread per (tile, 4 channels): 36 float4 loads (the 6x6 patch; neighbours' overlaps are L1/L2 hits),
+// columns then rows of B^T d B, 36 float4 stores.
+__global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                       int B, int H, int W, int C, long ntile_pad) {
+  const int th = H >> 2, tw = (W + 3) >> 2, C4 = C >> 2;
+  const long total = (long)B * th * tw * C4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th);
+    const int b = (int)(r / th);
+    f32x4 u[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {   // column j of the patch -> column j of B^T d
+      const int xx = 4 * tx - 1 + j;
+      const bool okx = (unsigned)xx < (unsigned)W;
+      const float* px = x + ((long)b * H * W + (okx ? xx : 0)) * C + c4 * 4;
+      f32x4 d[6], c[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int yy = 4 * ty - 1 + k;
+        const bool ok = okx && (unsigned)yy < (unsigned)H;
+        d[k] = ok ? *(const f32x4*)(px + (long)yy * W * C) : z;
+      }
+      wino4_bt(d, c);
+#pragma unroll
+      for (int k = 0; k < 6; k++) u[k][j] = c[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      f32x4 v[6];
+      wino4_bt(u[k], v);
+      float* o = V + ((long)(k * 6) * ntile_pad + t) * C + c4 * 4;
+#pragma unroll
+      for (int j = 0; j < 6; j++) *(f32x4*)(o + (long)j * ntile_pad * C) = v[j];
+    }
+  }
+}
+
+// One thread per (tile, 4 output channels): 36 float4 loads, A^T m A, bias + activation + width mask,
+// 16 float4 stores (or the 4 maxima of the 2x2 pool windows inside the tile).
+__global__ __launch_bounds__(256) void wino4_out_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
+                                                        float* __restrict__ y, const int32_t* __restrict__ wvalid,
+                                                        int B, int H, int W, int Co, int act, int pool,
+                                                        long ntile_pad) {
+  const int th = H >> 2, tw = (W + 3) >> 2, C4 = Co >> 2;
+  const long total = (long)B * th * tw * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th);
+    const int b = (int)(r / th);
+    f32x4 s[4][6];   // A^T m
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      f32x4 m[6], c[4];
+#pragma unroll
+      for (int k = 0; k < 6; k++) m[k] = *(const f32x4*)(Mo + ((long)(k * 6 + j) * ntile_pad + t) * Co + c4 * 4);
+      wino4_at(m, c);
+#pragma unroll
+      for (int k = 0; k < 4; k++) s[k][j] = c[k];
+    }
+    const f32x4 bs = *(const f32x4*)(bias + c4 * 4);
+    const int wv = wvalid ? wvalid[b] : W;
+    f32x4 o[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      wino4_at(s[k], o[k]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int xx = 4 * tx + j;
+        f32x4 v = o[k][j] + bs;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float e = v[c];
+          if (act == 1) e = e > 0.f ? e : 0.f;
+          else if (act == 2) e = e > 0.f ? e : 0.2f * e;
+          if (xx >= wv) e = 0.f;
+          v[c] = e;
+        }
+        o[k][j] = v;
+      }
+    }
+    if (pool) {
+      const int Wp = W >> 1, Hp = H >> 1;
+#pragma unroll
+      for (int pi = 0; pi < 2; pi++)
+#pragma unroll
+        for (int pj = 0; pj < 2; pj++) {
+          const int xp = 2 * tx + pj;
+          if (xp >= Wp) continue;   // odd W: the last column has no pool window
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+            v[c] = fmaxf(fmaxf(o[2 * pi][2 * pj][c], o[2 * pi][2 * pj + 1][c]),
+                         fmaxf(o[2 * pi + 1][2 * pj][c], o[2 * pi + 1][2 * pj + 1][c]));
+          *(f32x4*)(y + (((long)b * Hp + 2 * ty + pi) * Wp + xp) * Co + c4 * 4) = v;
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int xx = 4 * tx + j;
+          if (xx < W) *(f32x4*)(y + (((long)b * H + 4 * ty + k) * W + xx) * Co + c4 * 4) = o[k][j];
+        }
+    }
+  }
+}
+
+// The 36 GEMMs M[c] = V[c] U[c]^T as ONE persistent launch.  Work unit = (component, 128 tiles, TBN channels),
+// K = Cin; unit u = (component * ntm + m-tile) * ntn + n-tile.  Block L takes units L, L + G, L + 2G, ...:
+// the launch is G = one block per CU slot, every block gets the same number of units (+-1) -- no partly filled
+// last round -- and at any moment the blocks work on G consecutive units, i.e. on one or two components, so
+// the U slice and the V tiles that several units share are L2 hits (the XCD-aware block order keeps the units
+// that share a V tile on one XCD).  Inside a block the K steps of all its units form one flat loop over the
+// same three-stage direct-to-LDS pipeline as wino_gemm_dma_kernel: the loader walks into the next unit while
+// the MFMAs finish the current one, whose product is stored straight from the accumulators.
+template <int NWN>
+__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino4_gemm_kernel(const Wino4Gemm p) {
+  constexpr int NT = 128 * NWN, TBM = 128, TBN = 32 * NWN, SA = TBM * 32, SB = TBN * 32, NLA = TBM * 8 / NT;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];   // [B0 B1 B2 | A0 A1 A2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
+  const int NU = 36 * ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+
+  unsigned aoff[NLA], boff[2];
+#pragma unroll
+  for (int i = 0; i < NLA; i++) {
+    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+    aoff[i] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+    boff[i] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
+  }
+  const int nk = p.Cin / BK;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;
+  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  };
+  // unit -> operand bases (wave uniform)
+  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) {
+    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
+    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.Cin * 4ull;
+    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.Cin * 4ull;
+    m = (unsigned long long)p.M +
+        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
+  };
+  int l_u = L, l_k0 = 0;
+  unsigned long long pa, pb, pm_unused;
+  bases(l_u, pa, pb, pm_unused);
+  auto gload = [&](int stage) {
+    const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+    const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+    const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
+#pragma unroll
+    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], l_k0 * 4);
+#pragma unroll
+    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * NT * 16, boff[i], l_k0 * 4);
+    l_k0 += BK;
+    if (l_k0 == p.Cin) {   // next unit of this block (past the last one: re-read it into a stage nobody reads)
+      l_k0 = 0;
+      if (l_u + G < NU) l_u += G;
+      unsigned long long pm;
+      bases(l_u, pa, pb, pm);
+    }
+  };
+
+  int aaddr[4], baddr[4];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int kg = 0; kg < 4; kg++) {
+      aaddr[kg] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (2 * kg + h)) ^ ((Ra >> 1) & 15)) << 2);
+      baddr[kg] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (2 * kg + h)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+  int kc = 0, c_u = L;
+  // this lane's element of the 128 x TBN product: row wm*64 + 4*(lane>>5) (+ mt*32 + 8*(r>>2) + (r&3)), column
+  const unsigned moff = (unsigned)((wm * 64 + 4 * (lane >> 5)) * p.N + wn * 32 + (lane & 31));
+  auto flush = [&]() {
+    unsigned long long ua, ub, pm;
+    bases(c_u, ua, ub, pm);
+    float* dst = (float*)pm + moff;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        dst[(mt * 32 + 8 * (r >> 2) + (r & 3)) * p.N] = acc[mt][r];
+        acc[mt][r] = 0.f;
+      }
+    kc = 0;
+    c_u += G;
+  };
+
+  f32x4 a0[2], a1[2], b0[2];
+  auto frag = [&](int stage, int kg, int set) {
+    const float* sa = smem + 3 * SB + stage * SA;
+    const float* sb = smem + stage * SB;
+    a0[set] = *(const f32x4*)(sa + aaddr[kg]);
+    a1[set] = *(const f32x4*)(sa + aaddr[kg] + 1024);
+    b0[set] = *(const f32x4*)(sb + baddr[kg]);
+  };
+  auto mfma8 = [&](int set) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[set][j], b0[set][j], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[set][j], b0[set][j], acc[1], 0, 0, 0);
+    }
+  };
+  auto step = [&](auto ST) {
+    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
+    frag(st, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // the next step's loads were issued two steps ago; loads return in order among themselves, so at most one
+    // step's worth of outstanding operations (product stores of a flush included) means they have landed
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));
+    __syncthreads();
+    gload(st);
+    frag(nx, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kc == nk) flush();
+  };
+
+  const int nit = my_units * nk;
+  gload(0);
+  gload(1);
+  gload(2);
+  constexpr int LPS = NLA + 2;
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));
+  __syncthreads();
+  frag(0, 0, 0);
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // no LDS write may be in flight when the block ends
+}
+
+void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
+  static const int shape = getenv("CRNN_WINO4_SHAPE") ? atoi(getenv("CRNN_WINO4_SHAPE")) : 4;
+  const int nwn = (shape == 2 || p.N % 128) ? 2 : 4;
+  const int units = 36 * (p.ntile_pad / 128) * (p.N / (32 * nwn));
+  const int slots = nwn == 2 ? 512 : 256;
+  const int g = units < slots ? 8 * ((units + 7) / 8) : slots;
+  if (nwn == 2) hipLaunchKernelGGL((wino4_gemm_kernel<2>), dim3(g), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((wino4_gemm_kernel<4>), dim3(g), dim3(512), 0, s, p);
+}
+void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s) {
+  const long total = wino4_tiles(B, H, W) * (C / 4);
+  hipLaunchKernelGGL(wino4_in_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, x, V, B, H, W, C,
+                     wino4_pad(wino4_tiles(B, H, W)));
+}
+void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
+                      int Cout, int act, int pool, hipStream_t s) {
+  const long total = wino4_tiles(B, H, W) * (Cout / 4);
+  hipLaunchKernelGGL(wino4_out_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, M, bias, y, wvalid, B, H, W, Cout,
+                     act, pool, wino4_pad(wino4_tiles(B, H, W)));
+}
+
+// ---------------------------------------------------------------------------
 // conv0 + ReLU + pool0, direct.  16 pooled pixels x 16 channel groups (4 ch)
 // per 256-thread block; each thread keeps its 9x4 weights in registers, reads a
 // 4x4 input patch and writes one float4 of the NHWC output (256 B per pixel).

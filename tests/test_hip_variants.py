@@ -1,7 +1,7 @@
 """GPU: every selectable kernel variant of the Winograd stage gives the reference's strings.
 
 The variants are chosen by environment variables the library reads once per process
-(CRNN_WINOGRAD mask, CRNN_WINO_FUSED, CRNN_WINO_DMA tile shape / staging), so each runs in a child
+(CRNN_WINOGRAD_F4 / CRNN_WINOGRAD masks, CRNN_WINO_FUSED, CRNN_WINO_DMA / CRNN_WINO4_SHAPE tile shapes), so each runs in a child
 process; the child prints the decoded strings of the synthetic 32x280 golden lines and of the
 variable-width English-head lines, and the parent compares them with the goldens captured from the
 reference (tests/golden/make_golden.py)."""
@@ -32,16 +32,21 @@ out = {"text": zh.predict_lines(list(G["syn280/text/gray"])),
 print("RESULT " + json.dumps(out))
 """
 
+F2 = {"CRNN_WINOGRAD_F4": "0"}   # F(4x4) off: conv1-5 all go through the F(2x2) / direct variants below
 VARIANTS = [
-    ({"CRNN_WINOGRAD": "0"}, 1),                              # direct implicit GEMM everywhere
-    ({"CRNN_WINO_FUSED": "0"}, 1),                            # three-kernel Winograd (batched GEMM + output transform)
-    ({"CRNN_WINO_DMA": "0"}, 1),                              # fused, register-staged operands
-    ({"CRNN_WINO_DMA": "1"}, 1),                              # fused, direct-to-LDS, 128x64 tiles
-    ({"CRNN_WINO_DMA": "2"}, 1),                              # 128x128 tiles
-    ({"CRNN_WINO_DMA": "3"}, 1),                              # 64x64 tiles
-    ({}, 1),                                                  # per-launch choice, one lane
-    ({}, 4),                                                  # per-launch choice, lanes sharing the device
-    ({"CRNN_WINOGRAD": "0x38"}, 2),                           # Winograd on conv3-5 only
+    ({**F2, "CRNN_WINOGRAD": "0"}, 1),                        # direct implicit GEMM everywhere
+    ({**F2, "CRNN_WINO_FUSED": "0"}, 1),                      # three-kernel F(2x2) (batched GEMM + output transform)
+    ({**F2, "CRNN_WINO_DMA": "0"}, 1),                        # fused F(2x2), register-staged operands
+    ({**F2, "CRNN_WINO_DMA": "1"}, 1),                        # fused F(2x2), direct-to-LDS, 128x64 tiles
+    ({**F2, "CRNN_WINO_DMA": "2"}, 1),                        # 128x128 tiles
+    ({**F2, "CRNN_WINO_DMA": "3"}, 1),                        # 64x64 tiles
+    (F2, 4),                                                  # F(2x2) per-launch tile choice, lanes sharing the device
+    ({**F2, "CRNN_WINOGRAD": "0x38"}, 2),                     # F(2x2) on conv3-5 only
+    ({}, 1),                                                  # default: F(4x4) on conv2-5, fused F(2x2) on conv1
+    ({}, 4),
+    ({"CRNN_WINOGRAD_F4": "0x3E"}, 2),                        # F(4x4) on conv1 too (pool1 in its output transform)
+    ({"CRNN_WINO4_SHAPE": "2"}, 1),                           # F(4x4) GEMM units of 128x64
+    ({"CRNN_WINOGRAD_F4": "0x30", "CRNN_WINOGRAD": "0x08"}, 1),   # F(4x4) conv4-5, F(2x2) conv3, direct conv1-2
 ]
 
 
@@ -50,7 +55,7 @@ VARIANTS = [
 def test_variant_strings_match_reference_goldens(env, lanes, golden):
     _, M = golden
     e = dict(os.environ)
-    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA"):
+    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA", "CRNN_WINOGRAD_F4", "CRNN_WINO4_SHAPE", "CRNN_WINO4_MIN_N"):
         e.pop(k, None)
     e.update(env)
     code = CHILD % (ROOT, os.path.join(ROOT, "tests", "golden", "crnn_golden.npz"),

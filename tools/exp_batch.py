@@ -24,5 +24,6 @@ for n in [int(a) for a in sys.argv[1:]]:
             for name, ms, fl, by in m.kernel_times():
                 a = acc.setdefault(name, [0.0, fl]); a[0] += ms / 5
     tot = sum(v[0] for v in acc.values())
-    print("n=%d total %.3f ms (%.1f us/line)  " % (n, tot, tot * 1e3 / n) +
+    c15 = sum(v[0] for k, v in acc.items() if k[:5] in ("conv1", "conv2", "conv3", "conv4", "conv5"))
+    print("n=%d total %.3f ms (%.1f us/line) conv1-5 incl. transforms %.3f ms  " % (n, tot, tot * 1e3 / n, c15) +
           "  ".join("%s %.3f ms %.0f TF" % (k, v[0], v[1] / v[0] / 1e9) for k, v in acc.items() if v[1] and "rec" not in k))
