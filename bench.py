@@ -205,12 +205,16 @@ def main():
     value = lines_total / elapsed
     gemm_names = [n for n in order if (n.startswith("conv") and n != "conv0_pool0" and not n.endswith(("_win", "_wout", "_win4", "_wout4")))
                   or n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
-    # two GEMM kernels on the fp32 path: layers with a "<layer>_win" launch run through the fused
-    # Winograd kernel (wino_gemm_kernel), the rest through conv_gemm_kernel.  The roofline object is
-    # for whichever takes more of the step (rocprof's per-kernel average is over the same launches).
+    # GEMM kernels of the fp32 path: conv2-5 run as Winograd F(4x4) ("<layer>_f4": wino4_gemm_kernel), conv1 as
+    # fused F(2x2) (a "<layer>_win" launch precedes it: wino_gemm_dma_kernel), the LSTM input projections and the
+    # classifier on lin_gemm_kernel (same persistent direct-to-LDS pipeline as wino4_gemm_kernel), conv6 and the
+    # embedding on conv_gemm_kernel.  The roofline object is for whichever kernel takes most of the step
+    # (rocprof's per-kernel average is over the same launches).
     wino_names = [n for n in gemm_names if (n.split("_")[0] + "_win") in order]
     wino4_names = [n for n in gemm_names if n.endswith("_f4")]
-    direct_names = [n for n in gemm_names if n not in wino_names and n not in wino4_names]
+    lin_on = args.precision == "fp32" and os.environ.get("CRNN_LIN_GEMM", "1") != "0"
+    lin_names = [n for n in gemm_names if lin_on and n in ("lstm0_ih", "lstm1_ih", "classifier")]
+    direct_names = [n for n in gemm_names if n not in wino_names + wino4_names + lin_names]
     direct_kernel = "conv_gemm_kernel" if args.precision == "fp32" else "conv_gemm_bf16_kernel"
 
     def family(kernel, names, what):
@@ -231,7 +235,11 @@ def main():
         fams.append(family("wino4_gemm_kernel", wino4_names,
                            "Winograd F(4x4,3x3): the 36 component GEMMs of a layer as one persistent launch of 128x128 "
                            "units, executed MFMA FLOPs"))
-    fams.append(family(direct_kernel, direct_names, "implicit-GEMM conv + LSTM input projections + embedding + classifier"))
+    if lin_names:
+        fams.append(family("lin_gemm_kernel", lin_names, "LSTM input projections + classifier with fused arg-max, "
+                           "persistent launch of 128x128 units"))
+    fams.append(family(direct_kernel, direct_names, "implicit-GEMM conv6 + embedding" if lin_names else
+                       "implicit-GEMM conv + LSTM input projections + embedding + classifier"))
     fams.sort(key=lambda f: -f["ms_per_step"])
     dom = fams[0]
     gemm_names = dom["launches"]

@@ -80,6 +80,7 @@ struct crnn_handle {
   std::vector<float> h_wino4[7];
   unsigned wino4_mask = 0;
   int wino4_min_n = 1;
+  bool lin_gemm = true;   // LSTM input projections and classifier on lin_gemm_kernel (CRNN_LIN_GEMM=0: conv_gemm_kernel)
   // recurrence: batches of up to split_max lines (8 workgroups per 16 lines: 192 of the 256 CUs at 384) use the
   // hidden-split latency kernel in the synchronous host paths (CRNN_LSTM_SPLIT=<max lines>, 0 = never)
   int split_max = 384;
@@ -361,7 +362,7 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
   p.logits = take(n * g.T * (size_t)h->cfg.nclass);
   p.wl = (int32_t*)take(8 * n);
   p.raw = (int32_t*)take(n * g.T);
-  const size_t ntn = ((size_t)h->cfg.nclass + 127) / 128;
+  const size_t ntn = 4 * (((size_t)h->cfg.nclass + 127) / 128);   // lin_gemm_kernel: one partial per 32 columns
   p.pmax = take(n * g.T * ntn);
   p.pidx = (int32_t*)take(n * g.T * ntn);
   {
@@ -401,6 +402,11 @@ void kmark(crnn_handle* h, const char* name, double flop, double bytes) {
   (void)hipEventRecord(tl_cur->kev[tl_cur->nk], tl_cur->stream);
 }
 
+// fp32 GEMMs with at least 256 units' worth of columns x rows... go through the persistent direct-to-LDS kernel
+// (CRNN_LIN_GEMM=0: all through conv_gemm_kernel).  The arg-max partial layout depends on the kernel, so the
+// choice for the classifier must be the same in gemm() and in the reduction that follows: lin_partials().
+static bool use_lin_gemm(const crnn_handle* h, const ConvGemm& p) { return h->lin_gemm && p.N >= 512 && lin_gemm_ok(p); }
+
 // out_bf16 only matters on the bf16 path (which GEMM outputs feed another GEMM)
 void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, const uint16_t* Wt16,
           const float* bias, void* C, int M, int N, int K, bool out_bf16, float* pmax = nullptr,
@@ -412,6 +418,7 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
   p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
   p.pmax = pmax; p.pidx = pidx;
   if (b16) launch_conv_gemm_bf16(p, out_bf16, tl_cur->stream);
+  else if (use_lin_gemm(h, p)) launch_lin_gemm(p, tl_cur->stream);
   else launch_conv_gemm(p, tl_cur->stream);
   const double es = b16 ? 2.0 : 4.0;
   kmark(h, name, 2.0 * M * N * K,
@@ -576,7 +583,13 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   }
   HIPCHK(h, hipEventRecord(tl_cur->ev[3], s));
   // the classifier's epilogue left per-tile (max, index) partials: finish the arg-max over tiles
-  const int ntn = (h->cfg.nclass + 127) / 128;
+  // partials per row: one per 128 columns from conv_gemm_kernel, one per 32 from lin_gemm_kernel
+  int ntn = (h->cfg.nclass + 127) / 128;
+  {
+    ConvGemm q{};
+    q.M = M; q.N = h->cfg.nclass; q.K = 512; q.ks = 1;
+    if (!b16 && use_lin_gemm(h, q)) ntn *= 4;
+  }
   launch_argmax_partials(p.pmax, p.pidx, p.raw, M, ntn, s);
   kmark(h, "argmax", 0, 8.0 * M * ntn + 4.0 * M);
   launch_ctc(p.raw, tlen, d_lab, d_len, n, g.T, s);
@@ -725,6 +738,7 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   h->wino4_mask = cfg->precision == CRNN_FP32 ? 0x3Cu : 0u;
   if (const char* e = getenv("CRNN_WINOGRAD_F4")) h->wino4_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
   if (const char* e = getenv("CRNN_WINO4_MIN_N")) h->wino4_min_n = atoi(e);
+  if (const char* e = getenv("CRNN_LIN_GEMM")) h->lin_gemm = atoi(e) != 0;
   if (const char* e = getenv("CRNN_LSTM_SPLIT")) h->split_max = atoi(e);
   if (const char* e = getenv("CRNN_WINOGRAD")) h->wino_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
   for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);

@@ -31,6 +31,10 @@ struct ConvGemm {
 };
 
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
+// Plain GEMMs (ks == 1) on the persistent direct-to-LDS kernel; with pmax set the arg-max partials are
+// [M][4 * ceil(N/128)] (one per 32-column group).  lin_gemm_ok: shape fits that kernel.
+bool lin_gemm_ok(const ConvGemm& p);
+void launch_lin_gemm(const ConvGemm& p, hipStream_t s);
 
 #ifdef __HIPCC__
 // Arg-max epilogue shared by the fp32 and bf16 GEMM kernels.  acc is the wave's 2x2 set of 32x32

@@ -967,18 +967,23 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino4_gemm_kernel
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
   int kc = 0, c_u = L;
-  // this lane's element of the 128 x TBN product: row wm*64 + 4*(lane>>5) (+ mt*32 + 8*(r>>2) + (r&3)), column
-  const unsigned moff = (unsigned)((wm * 64 + 4 * (lane >> 5)) * p.N + wn * 32 + (lane & 31));
-  auto flush = [&]() {
+  // The MFMAs take the U fragment as their first operand, so the product sits transposed in the accumulators:
+  // lane & 31 = tile (row of M), register r = channel 8 (r >> 2) + 4 half + (r & 3) -- a lane owns four
+  // consecutive channels of one row per register quad and stores them as 16 bytes (8 stores per unit and wave
+  // instead of 32: the stores share the memory pipeline and vmcnt with the operand loads).
+  const unsigned moff = (unsigned)((wm * 64 + (lane & 31)) * p.N + wn * 32 + 4 * (lane >> 5));
+  auto flush = [&]() __attribute__((always_inline)) {
     unsigned long long ua, ub, pm;
     bases(c_u, ua, ub, pm);
     float* dst = (float*)pm + moff;
 #pragma unroll
     for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        dst[(mt * 32 + 8 * (r >> 2) + (r & 3)) * p.N] = acc[mt][r];
-        acc[mt][r] = 0.f;
+      for (int g = 0; g < 4; g++) {
+        const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+        *(f32x4*)(dst + mt * 32 * p.N + 8 * g) = v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[mt][4 * g + e] = 0.f;
       }
     kc = 0;
     c_u += G;
@@ -995,8 +1000,8 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino4_gemm_kernel
   auto mfma8 = [&](int set) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[set][j], b0[set][j], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[set][j], b0[set][j], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[set][j], a0[set][j], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[set][j], a1[set][j], acc[1], 0, 0, 0);
     }
   };
   auto step = [&](auto ST) {
@@ -1044,6 +1049,234 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino4_gemm_kernel
   if (it + 1 < nit) step(std::integral_constant<int, 1>{});
   __builtin_amdgcn_s_waitcnt(0x0F70);     // no LDS write may be in flight when the block ends
 }
+
+// ---------------------------------------------------------------------------
+// Plain GEMM C = act(A W^T + bias) on the same persistent direct-to-LDS pipeline (LSTM input projections and
+// the classifier: M = lines x T rows, K = 256 / 512).  Units of 128 x 128, unit u = m-tile * ntn + n-tile,
+// block L takes units L, L + G, ...; rows past M / N are clamped in the loader and dropped in the epilogue.
+// The bias sits in LDS (a global load in the epilogue would make the compiler wait for vmcnt(0), i.e. for
+// every operand load in flight).  ARGMAX: instead of (or besides) C, every wave reduces its 64 x 32 piece to
+// (max, lowest column) per row and writes one partial per row and 32-column group,
+// pmax / pidx[row][n-tile * 4 + wave column]; launch_argmax_partials finishes the reduction.
+// ---------------------------------------------------------------------------
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte store at a 4-byte aligned address
+constexpr int LIN_MAXN = 8192;   // bias columns held in LDS (32 KB beside the 96 KB of stages)
+template <bool ARGMAX>
+__global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
+  constexpr int NWN = 4, NT = 512, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32, NLA = 2;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];   // [B0 B1 B2 | A0 A1 A2]
+  __shared__ float sbias[LIN_MAXN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int ntn = (p.N + TBN - 1) / TBN, ntm = (p.M + TBM - 1) / TBM;
+  const int NU = ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  for (int i = tid; i < ntn * TBN; i += NT) sbias[i] = i < p.N ? p.bias[i] : 0.f;
+  __syncthreads();
+
+  // loader: local row and k-chunk byte offset of this lane's LDS chunk positions
+  int lrow[2];
+  unsigned lkb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+    lrow[i] = 2 * S + (c16 >> 3);
+    lkb[i] = (unsigned)((c16 & 7) * 16);
+  }
+  unsigned aoff[2], boff[2];
+  auto offsets = [&](int u) __attribute__((always_inline)) {
+    const int mt = u / ntn, nt = u - mt * ntn;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      int m = mt * TBM + lrow[i], n = nt * TBN + lrow[i];
+      m = m < p.M ? m : p.M - 1;
+      n = n < p.N ? n : p.N - 1;
+      aoff[i] = (unsigned)m * (unsigned)(p.K * 4) + lkb[i];
+      boff[i] = (unsigned)n * (unsigned)(p.K * 4) + lkb[i];
+    }
+  };
+  const int nk = p.K / BK;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;
+  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  };
+  const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.Wt;
+  int l_u = L, l_k0 = 0;
+  offsets(l_u);
+  auto gload = [&](int stage) __attribute__((always_inline)) {
+    const i32x4 a_rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa),
+                          __builtin_amdgcn_readfirstlane((int)((pa >> 32) & 0xFFFF)), 0x7FFFFFFF, 0x00020000};
+    const i32x4 b_rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)pb),
+                          __builtin_amdgcn_readfirstlane((int)((pb >> 32) & 0xFFFF)), 0x7FFFFFFF, 0x00020000};
+    const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
+    const int soff = __builtin_amdgcn_readfirstlane(l_k0 * 4);
+#pragma unroll
+    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], soff);
+#pragma unroll
+    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * NT * 16, boff[i], soff);
+    l_k0 += BK;
+    if (l_k0 == p.K) {   // next unit of this block (past the last one: re-read it into a stage nobody reads)
+      l_k0 = 0;
+      if (l_u + G < NU) l_u += G;
+      offsets(l_u);
+    }
+  };
+
+  int aaddr[4], baddr[4];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int kg = 0; kg < 4; kg++) {
+      aaddr[kg] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (2 * kg + h)) ^ ((Ra >> 1) & 15)) << 2);
+      baddr[kg] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (2 * kg + h)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+  int kc = 0, c_u = L;
+  const int act = p.act, half = lane >> 5;
+  const int ntp = ntn * NWN;
+  // The MFMAs take the weight fragment as their first operand, so the product sits transposed in the
+  // accumulators: lane & 31 = row (m) of the 32-row sub-tile, register r = column 8 (r >> 2) + 4 half + (r & 3).
+  // A lane then owns four consecutive columns of one row per register quad (16-byte stores), and the row's
+  // arg-max over the wave's 32 columns is an in-lane scan plus one exchange between the half-waves.
+  auto flush = [&]() __attribute__((always_inline)) {
+    const int mt = c_u / ntn, nt = c_u - mt * ntn;
+    const int col0 = nt * TBN + wn * 32 + 4 * half;
+#pragma unroll
+    for (int m2 = 0; m2 < 2; m2++) {
+      const int row = mt * TBM + wm * 64 + m2 * 32 + (lane & 31);
+      float bestv = -INFINITY;
+      int besti = 0;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int col = col0 + 8 * g;
+        const f32x4 bias = *(const f32x4*)(sbias + col);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v[e] = acc[m2][4 * g + e] + bias[e];
+          acc[m2][4 * g + e] = 0.f;
+          if (ARGMAX) {
+            const float vv = col + e < p.N ? v[e] : -INFINITY;
+            const bool up = vv > bestv;          // ascending columns, strict: the lowest column keeps a tie
+            bestv = up ? vv : bestv;
+            besti = up ? col + e : besti;
+          }
+        }
+        if (!ARGMAX || p.C) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float neg = act == 2 ? 0.2f * v[e] : (act == 1 ? 0.f : v[e]);
+            v[e] = v[e] > 0.f ? v[e] : neg;
+          }
+          if (row < p.M) {
+            float* dst = p.C + (long)row * p.ldc + col;
+            if (col + 3 < p.N) *(f32x4u*)dst = v;
+            else {
+#pragma unroll
+              for (int e = 0; e < 4; e++)
+                if (col + e < p.N) dst[e] = v[e];
+            }
+          }
+        }
+      }
+      if (ARGMAX) {
+        const float ov = __shfl_xor(bestv, 32);
+        const int oi = __shfl_xor(besti, 32);
+        const bool take = ov > bestv || (ov == bestv && oi < besti);
+        bestv = take ? ov : bestv;
+        besti = take ? oi : besti;
+        if (half == 0 && row < p.M) {
+          p.pmax[(long)row * ntp + nt * NWN + wn] = bestv;
+          p.pidx[(long)row * ntp + nt * NWN + wn] = besti;
+        }
+      }
+    }
+    kc = 0;
+    c_u += G;
+  };
+
+  f32x4 a0[2], a1[2], b0[2];
+  auto frag = [&](int stage, int kg, int set) __attribute__((always_inline)) {
+    const float* sa = smem + 3 * SB + stage * SA;
+    const float* sb = smem + stage * SB;
+    a0[set] = *(const f32x4*)(sa + aaddr[kg]);
+    a1[set] = *(const f32x4*)(sa + aaddr[kg] + 1024);
+    b0[set] = *(const f32x4*)(sb + baddr[kg]);
+  };
+  auto mfma8 = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[set][j], a0[set][j], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[set][j], a1[set][j], acc[1], 0, 0, 0);
+    }
+  };
+  auto step = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
+    frag(st, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // see wino4_gemm_kernel
+    __syncthreads();
+    gload(st);
+    frag(nx, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kc == nk) flush();
+  };
+
+  const int nit = my_units * nk;
+  gload(0);
+  gload(1);
+  gload(2);
+  constexpr int LPS = NLA + 2;
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));
+  __syncthreads();
+  frag(0, 0, 0);
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // no LDS write may be in flight when the block ends
+}
+
+bool lin_gemm_ok(const ConvGemm& p) {
+  // plain GEMM, K a multiple of 32, byte offsets below 2 GiB, bias of all n-tiles fits in LDS
+  const long ntn = (p.N + 127) / 128;
+  return p.ks == 1 && p.nbatch <= 1 && !p.wvalid && p.K % 32 == 0 && p.M > 0 && p.N > 0 &&
+         (double)p.M * p.K * 4 < 2147000000.0 && (double)p.N * p.K * 4 < 2147000000.0 && ntn * 128 <= LIN_MAXN;
+}
+
+void launch_lin_gemm(const ConvGemm& p, hipStream_t s) {
+  const int ntn = (p.N + 127) / 128, units = ((p.M + 127) / 128) * ntn;
+  const int g = units < 256 ? 8 * ((units + 7) / 8) : 256;
+  if (p.pmax) hipLaunchKernelGGL((lin_gemm_kernel<true>), dim3(g), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((lin_gemm_kernel<false>), dim3(g), dim3(512), 0, s, p);
+}
+
 
 void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
   static const int shape = getenv("CRNN_WINO4_SHAPE") ? atoi(getenv("CRNN_WINO4_SHAPE")) : 4;
@@ -1540,22 +1773,30 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
 __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __restrict__ pmax,
                                                               const int32_t* __restrict__ pidx,
                                                               int32_t* __restrict__ idx, int M, int nt) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per row: lanes stride over the row's partials (coalesced), then a butterfly; ties -> lowest column
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* pv = pmax + (long)row * nt;
   const int32_t* pi = pidx + (long)row * nt;
-  float bv = pv[0];
-  int bi = pi[0];
-  for (int t = 1; t < nt; t++) {       // tiles are in column order: strict > keeps the lowest index
+  float bv = -INFINITY;
+  int bi = 0x7FFFFFFF;
+  for (int t = lane; t < nt; t += 64) {
     const float v = pv[t];
-    if (v > bv) { bv = v; bi = pi[t]; }
+    const int i = pi[t];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
   }
-  idx[row] = bi;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) idx[row] = bi == 0x7FFFFFFF ? 0 : bi;
 }
 
 void launch_argmax_partials(const float* pmax, const int32_t* pidx, int32_t* idx, int M, int ntiles,
                             hipStream_t s) {
-  hipLaunchKernelGGL(argmax_partials_kernel, dim3((M + 255) / 256), dim3(256), 0, s, pmax, pidx, idx, M, ntiles);
+  hipLaunchKernelGGL(argmax_partials_kernel, dim3((M + 3) / 4), dim3(256), 0, s, pmax, pidx, idx, M, ntiles);
 }
 
 void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld, hipStream_t s) {

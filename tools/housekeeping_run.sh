@@ -5,7 +5,7 @@ timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $O/st_l1 -o s --output-for
 timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $O/st_l3 -o s --output-format csv -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline > $O/st_l3.json 2> $O/st_l3.err
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_f -o f --output-format csv -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_f.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_w -o w --output-format csv -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_w.log 2>&1
-python tools/pmc_traffic.py $O/pmc_f $O/pmc_w profiles/r1_pmc_traffic_fp32.json hybrid > $O/traffic.txt
+python tools/pmc_traffic.py $O/pmc_f $O/pmc_w profiles/r1_pmc_traffic_fp32.json f4 > $O/traffic.txt
 cp profiles/r1_pmc_traffic_fp32.json $O/traffic_fp32.json
 timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $O/pmc_m32 -o m --output-format csv -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_m32.log 2>&1
 python tools/pmc_mfma.py $O/pmc_m32 profiles/r1_pmc_mfma_fp32.json f32 > $O/mfma32.txt
