@@ -28,6 +28,7 @@ struct ConvGemm {
   // batched GEMM (Winograd: 16 independent GEMMs): blockIdx.y selects the batch; element strides
   int nbatch;         // 0 or 1 = not batched
   long bsA, bsW, bsC;
+  int gn;             // lin_gemm_kernel: column groups of the XCD split (set by launch_lin_gemm)
 };
 
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);

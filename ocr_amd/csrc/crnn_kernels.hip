@@ -1070,10 +1070,26 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
   const int wm = wave / NWN, wn = wave % NWN;
   const int ntn = (p.N + TBN - 1) / TBN, ntm = (p.M + TBM - 1) / TBM;
   const int NU = ntm * ntn, G = gridDim.x;
-  const int chunk = G >> 3;
-  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (L >= NU) return;
-  const int my_units = (NU - L + G - 1) / G;
+  // Which units this block takes.  Small launches (G < 256): unit L + k G, L the XCD-aware block order.
+  // Full launches: the 8 XCDs split the unit grid into gn column groups x 8/gn row groups, and the G/8 blocks
+  // of an XCD stride through their rectangle row-major -- the rectangle's slice of W stays in that XCD's L2
+  // and an A tile is fetched once per column group instead of once per XCD and n-tile.
+  int nb, ne, gw, mb, me, first, stride, my_units;
+  if (p.gn > 0 && G == 256) {
+    const int x = blockIdx.x & 7, gm = 8 / p.gn, cg = x % p.gn, rg = x / p.gn;
+    nb = cg * ntn / p.gn; ne = (cg + 1) * ntn / p.gn;
+    mb = rg * ntm / gm; me = (rg + 1) * ntm / gm;
+    first = blockIdx.x >> 3; stride = G >> 3;
+  } else {
+    const int chunk = G >> 3;
+    nb = 0; ne = ntn; mb = 0; me = ntm;
+    first = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3); stride = G;
+  }
+  gw = ne - nb;
+  const int NUx = gw * (me - mb);
+  if (first >= NUx) return;
+  my_units = (NUx - first + stride - 1) / stride;
+  (void)NU;
   for (int i = tid; i < ntn * TBN; i += NT) sbias[i] = i < p.N ? p.bias[i] : 0.f;
   __syncthreads();
 
@@ -1087,8 +1103,8 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
     lkb[i] = (unsigned)((c16 & 7) * 16);
   }
   unsigned aoff[2], boff[2];
-  auto offsets = [&](int u) __attribute__((always_inline)) {
-    const int mt = u / ntn, nt = u - mt * ntn;
+  auto offsets = [&](int q) __attribute__((always_inline)) {
+    const int qm = q / gw, mt = mb + qm, nt = nb + q - qm * gw;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       int m = mt * TBM + lrow[i], n = nt * TBN + lrow[i];
@@ -1105,7 +1121,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
                  :: "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
   };
   const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.Wt;
-  int l_u = L, l_k0 = 0;
+  int l_u = first, l_k0 = 0;
   offsets(l_u);
   auto gload = [&](int stage) __attribute__((always_inline)) {
     const i32x4 a_rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa),
@@ -1121,7 +1137,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
     l_k0 += BK;
     if (l_k0 == p.K) {   // next unit of this block (past the last one: re-read it into a stage nobody reads)
       l_k0 = 0;
-      if (l_u + G < NU) l_u += G;
+      if (l_u + stride < NUx) l_u += stride;
       offsets(l_u);
     }
   };
@@ -1140,7 +1156,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
   for (int mt = 0; mt < 2; mt++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
-  int kc = 0, c_u = L;
+  int kc = 0, c_u = first;
   const int act = p.act, half = lane >> 5;
   const int ntp = ntn * NWN;
   // The MFMAs take the weight fragment as their first operand, so the product sits transposed in the
@@ -1148,7 +1164,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
   // A lane then owns four consecutive columns of one row per register quad (16-byte stores), and the row's
   // arg-max over the wave's 32 columns is an in-lane scan plus one exchange between the half-waves.
   auto flush = [&]() __attribute__((always_inline)) {
-    const int mt = c_u / ntn, nt = c_u - mt * ntn;
+    const int qm = c_u / gw, mt = mb + qm, nt = nb + c_u - qm * gw;
     const int col0 = nt * TBN + wn * 32 + 4 * half;
 #pragma unroll
     for (int m2 = 0; m2 < 2; m2++) {
@@ -1201,7 +1217,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
       }
     }
     kc = 0;
-    c_u += G;
+    c_u += stride;
   };
 
   f32x4 a0[2], a1[2], b0[2];
@@ -1270,9 +1286,21 @@ bool lin_gemm_ok(const ConvGemm& p) {
          (double)p.M * p.K * 4 < 2147000000.0 && (double)p.N * p.K * 4 < 2147000000.0 && ntn * 128 <= LIN_MAXN;
 }
 
-void launch_lin_gemm(const ConvGemm& p, hipStream_t s) {
-  const int ntn = (p.N + 127) / 128, units = ((p.M + 127) / 128) * ntn;
+void launch_lin_gemm(const ConvGemm& p0, hipStream_t s) {
+  ConvGemm p = p0;
+  const int ntn = (p.N + 127) / 128, ntm = (p.M + 127) / 128, units = ntm * ntn;
   const int g = units < 256 ? 8 * ((units + 7) / 8) : 256;
+  // column groups: the fewest whose slice of W (N/gn x K floats) fits an XCD's 4 MB L2 with room for A tiles,
+  // provided every XCD's rectangle still has at least one unit per block
+  p.gn = 0;
+  static const int force = getenv("CRNN_LIN_GN") ? atoi(getenv("CRNN_LIN_GN")) : -1;
+  if (g == 256) {
+    for (int gn = 1; gn <= 8; gn *= 2) {
+      const double slice = (double)p.N * p.K * 4 / gn;
+      if ((slice <= 3.0e6 || gn == 8) && ntn >= gn && ntm >= 8 / gn && (ntn / gn) * (ntm / (8 / gn)) >= 32) { p.gn = gn; break; }
+    }
+    if (force >= 0) p.gn = force;
+  }
   if (p.pmax) hipLaunchKernelGGL((lin_gemm_kernel<true>), dim3(g), dim3(512), 0, s, p);
   else hipLaunchKernelGGL((lin_gemm_kernel<false>), dim3(g), dim3(512), 0, s, p);
 }
