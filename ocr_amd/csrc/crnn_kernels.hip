@@ -975,13 +975,16 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino4_gemm_kernel
   auto flush = [&]() __attribute__((always_inline)) {
     unsigned long long ua, ub, pm;
     bases(c_u, ua, ub, pm);
-    float* dst = (float*)pm + moff;
+    // global address space spelled out: a pointer made from an integer is generic, and FLAT stores also count
+    // in lgkmcnt, where the very next fragment-read wait would stall on them
+    typedef __attribute__((address_space(1))) f32x4 gf32x4;
+    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
 #pragma unroll
     for (int mt = 0; mt < 2; mt++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-        *(f32x4*)(dst + mt * 32 * p.N + 8 * g) = v;
+        *(gf32x4*)(dst + mt * 32 * p.N + 8 * g) = v;
 #pragma unroll
         for (int e = 0; e < 4; e++) acc[mt][4 * g + e] = 0.f;
       }
@@ -1048,6 +1051,169 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino4_gemm_kernel
   if (it < nit) step(std::integral_constant<int, 0>{});
   if (it + 1 < nit) step(std::integral_constant<int, 1>{});
   __builtin_amdgcn_s_waitcnt(0x0F70);     // no LDS write may be in flight when the block ends
+}
+
+// Same computation with a dedicated LOADER WAVE: a ninth wave issues all direct-to-LDS operand loads of the
+// block (32 per K step) and is the only one that waits on vmcnt; the eight MFMA waves only read fragments,
+// issue MFMAs and store finished products -- their stores no longer sit in the counter the operand pipeline
+// waits on, and they issue no load instructions at all.  One barrier per K step, executed by all nine waves:
+// before it the loader has seen the next step's operands land and every MFMA wave has read the current
+// stage into registers; after it the loader refills that stage for step + 3.
+__global__ __launch_bounds__(576, 1) void wino4_gemm_lw_kernel(const Wino4Gemm p) {
+  constexpr int NWN = 4, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];   // [B0 B1 B2 | A0 A1 A2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
+  const int NU = 36 * ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  const int nk = p.Cin / BK;
+  const int nit = my_units * nk;
+  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) __attribute__((always_inline)) {
+    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
+    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.Cin * 4ull;
+    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.Cin * 4ull;
+    m = (unsigned long long)p.M +
+        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
+  };
+
+  if (wave == 8) {
+    // ---------------- loader ----------------
+    // chunk position P = q * 64 + lane (q = 0..15) of a stage half holds (row, k-chunk) given by the swizzle
+    unsigned off[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int P = q * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      off[q] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+    auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                   :: "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    };
+    int l_u = L, l_k0 = 0;
+    unsigned long long pa, pb, pm;
+    bases(l_u, pa, pb, pm);
+    auto gload = [&](int stage) __attribute__((always_inline)) {
+      const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        dma(a_rsrc, sa + q * 1024, off[q], l_k0 * 4);
+        dma(b_rsrc, sb + q * 1024, off[q], l_k0 * 4);
+      }
+      l_k0 += BK;
+      if (l_k0 == p.Cin) {
+        l_k0 = 0;
+        if (l_u + G < NU) l_u += G;
+        bases(l_u, pa, pb, pm);
+      }
+    };
+    gload(0);
+    gload(1);
+    gload(2);
+    asm volatile("s_waitcnt vmcnt(63)" ::: "memory");   // 96 issued: at most 63 left => step 0 (the first 32) landed
+    __builtin_amdgcn_s_barrier();
+    int st = 0;
+#pragma unroll 1
+    for (int it = 0; it < nit; it++) {
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // step it + 1 landed (step it + 2 may be in flight)
+      __builtin_amdgcn_s_barrier();
+      if (st == 0) gload(0);
+      else if (st == 1) gload(1);
+      else gload(2);
+      st = st == 2 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS write may be in flight when the block ends
+    return;
+  }
+
+  // ---------------- MFMA waves ----------------
+  const int wm = wave / NWN, wn = wave % NWN;
+  int aaddr[4], baddr[4];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int kg = 0; kg < 4; kg++) {
+      aaddr[kg] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (2 * kg + h)) ^ ((Ra >> 1) & 15)) << 2);
+      baddr[kg] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (2 * kg + h)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+  int kc = 0, c_u = L;
+  const unsigned moff = (unsigned)((wm * 64 + (lane & 31)) * p.N + wn * 32 + 4 * (lane >> 5));
+  auto flush = [&]() __attribute__((always_inline)) {
+    unsigned long long ua, ub, pm;
+    bases(c_u, ua, ub, pm);
+    typedef __attribute__((address_space(1))) f32x4 gf32x4;
+    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+        *(gf32x4*)(dst + mt * 32 * p.N + 8 * g) = v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[mt][4 * g + e] = 0.f;
+      }
+    kc = 0;
+    c_u += G;
+  };
+  f32x4 a0[2], a1[2], b0[2];
+  auto frag = [&](int stage, int kg, int set) __attribute__((always_inline)) {
+    const float* sa = smem + 3 * SB + stage * SA;
+    const float* sb = smem + stage * SB;
+    a0[set] = *(const f32x4*)(sa + aaddr[kg]);
+    a1[set] = *(const f32x4*)(sa + aaddr[kg] + 1024);
+    b0[set] = *(const f32x4*)(sb + baddr[kg]);
+  };
+  auto mfma8 = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[set][j], a0[set][j], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[set][j], a1[set][j], acc[1], 0, 0, 0);
+    }
+  };
+  auto step = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
+    frag(st, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only: stage st is in registers (vmcnt / expcnt not waited)
+    __builtin_amdgcn_s_barrier();
+    frag(nx, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kc == nk) flush();
+  };
+  __builtin_amdgcn_s_barrier();
+  frag(0, 0, 0);
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------
@@ -1312,7 +1478,9 @@ void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
   const int units = 36 * (p.ntile_pad / 128) * (p.N / (32 * nwn));
   const int slots = nwn == 2 ? 512 : 256;
   const int g = units < slots ? 8 * ((units + 7) / 8) : slots;
+  static const int lw = getenv("CRNN_WINO4_LW") ? atoi(getenv("CRNN_WINO4_LW")) : 1;
   if (nwn == 2) hipLaunchKernelGGL((wino4_gemm_kernel<2>), dim3(g), dim3(256), 0, s, p);
+  else if (lw) hipLaunchKernelGGL(wino4_gemm_lw_kernel, dim3(g), dim3(576), 0, s, p);
   else hipLaunchKernelGGL((wino4_gemm_kernel<4>), dim3(g), dim3(512), 0, s, p);
 }
 void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s) {
