@@ -1,9 +1,14 @@
 #!/bin/bash
 set -e
 O=gpurun_out
-for v in 0 1 0 1; do
-  if [ $v = 1 ]; then export CRNN_DBG_SKIP_REC=1; else unset CRNN_DBG_SKIP_REC; fi
-  timeout -k 10 300 python bench.py --no-cpu-baseline > $O/x_$v.json 2> $O/x_$v.err
+run() {
+  name=$1; shift
+  env "$@" timeout -k 10 300 python bench.py --no-cpu-baseline --steps 40 > $O/h_$name.json 2> $O/h_$name.err
   python -c "
-import json; d = json.load(open('$O/x_$v.json')); print('skiprec $v', d['value'], d['ms_per_step'])"
+import json; d = json.load(open('$O/h_$name.json')); print('$name', d['value'], d['ms_per_step'])"
+}
+for r in 1 2 3 4; do
+run dflt CRNN_WINOGRAD_F4=0x3C
+run half CRNN_WINOGRAD_F4=0x3E
+run full CRNN_WINOGRAD_F4=0x3E CRNN_WINO4_HALF=0
 done
