@@ -203,7 +203,7 @@ def main():
     peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     lines_total = BATCH * args.steps * world
     value = lines_total / elapsed
-    gemm_names = [n for n in order if (n.startswith("conv") and n != "conv0_pool0" and not n.endswith(("_win", "_wout", "_win4", "_wout4")))
+    gemm_names = [n for n in order if (n.startswith("conv") and n != "conv0_pool0" and "_win" not in n and "_wout" not in n)
                   or n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
     # GEMM kernels of the fp32 path: conv1-5 run as Winograd F(4x4) ("<layer>_f4": wino4_gemm_lw_kernel; a layer
     # switched back to fused F(2x2) has a "<layer>_win" launch before it: wino_gemm_dma_kernel), the LSTM input projections and the

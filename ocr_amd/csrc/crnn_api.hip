@@ -428,7 +428,8 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
 // pool_out: where a following MaxPool 2x2/2 would write; the fused Winograd kernel can apply it
 // itself (one tile == one pool window).  Returns true when it did, so the caller skips the pool.
 bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
-          int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr, float* pool_out = nullptr) {
+          int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr, float* pool_out = nullptr,
+          float* pool21_out = nullptr) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   const bool b16 = h->cfg.precision == CRNN_BF16;
   if (!b16 && ((h->wino4_mask >> layer) & 1u) && wino_v && wino_m && use_wino4(h, n)) {
@@ -445,11 +446,16 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     w.V = wino_v; w.U = h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co; w.Cin = Cin;
     launch_wino4_gemm(w, s);
     kmark(h, wn4[1][layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * 36 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
-    launch_wino4_out(wino_m, h->d_conv_b[layer], pool_out ? pool_out : (float*)C, wvalid, n, Hin, Win, Co,
-                     h->cfg.leaky_relu ? 2 : 1, pool_out ? 1 : 0, s);
-    kmark(h, wn4[2][layer], 0,
-          4.0 * (36.0 * tiles * Co + (pool_out ? (double)n * (Hin / 2) * (Win / 2) : (double)n * Hin * Win) * Co));
-    return pool_out != nullptr;
+    static const bool fuse21 = !(getenv("CRNN_WINO4_POOL21") && atoi(getenv("CRNN_WINO4_POOL21")) == 0);
+    if (!fuse21) pool21_out = nullptr;
+    float* dst = pool_out ? pool_out : (pool21_out ? pool21_out : (float*)C);
+    launch_wino4_out(wino_m, h->d_conv_b[layer], dst, wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1,
+                     pool_out ? 1 : (pool21_out ? 2 : 0), s);
+    const double outpx = pool_out ? (double)n * (Hin / 2) * (Win / 2)
+                                  : (pool21_out ? (double)n * (Hin / 2) * (Win + 1) : (double)n * Hin * Win);
+    kmark(h, pool21_out ? (layer == 3 ? "conv3_wout4_pool2" : "conv5_wout4_pool3") : wn4[2][layer], 0,
+          4.0 * (36.0 * tiles * Co + outpx * Co));
+    return pool_out != nullptr || pool21_out != nullptr;
   }
   if (!b16 && ((h->wino_mask >> layer) & 1u) && wino_v) {
     // Winograd F(2x2,3x3): input transform, 16 batched GEMMs (K = Cin), output transform
@@ -534,15 +540,17 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     kmark(h, "pool1", 0, es * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
   }
   conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2, p.wv, p.wm);
-  conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2, p.wv, p.wm);
-  if (b16) launch_pool_2x2s21p01_bf16(p.c3, p.p2, n, 8, g.W2, 256, s);
-  else launch_pool_2x2s21p01(p.c3, p.p2, n, 8, g.W2, 256, s);
-  kmark(h, "pool2", 0, es * (dn * 8 * g.W2 * 256 + dn * 4 * g.W3 * 256));
+  if (!conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2, p.wv, p.wm, nullptr, p.p2)) {
+    if (b16) launch_pool_2x2s21p01_bf16(p.c3, p.p2, n, 8, g.W2, 256, s);
+    else launch_pool_2x2s21p01(p.c3, p.p2, n, 8, g.W2, 256, s);
+    kmark(h, "pool2", 0, es * (dn * 8 * g.W2 * 256 + dn * 4 * g.W3 * 256));
+  }
   conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3, p.wv, p.wm);
-  conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3, p.wv, p.wm);
-  if (b16) launch_pool_2x2s21p01_bf16(p.c5, p.p3, n, 4, g.W3, 512, s);
-  else launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
-  kmark(h, "pool3", 0, es * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
+  if (!conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3, p.wv, p.wm, nullptr, p.p3)) {
+    if (b16) launch_pool_2x2s21p01_bf16(p.c5, p.p3, n, 4, g.W3, 512, s);
+    else launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
+    kmark(h, "pool3", 0, es * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
+  }
   conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T);
   HIPCHK(h, hipEventRecord(tl_cur->ev[2], s));
   const int M = n * g.T;

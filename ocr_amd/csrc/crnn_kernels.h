@@ -181,6 +181,7 @@ inline long wino4_tiles(int B, int H, int W) { return (long)B * (H / 4) * ((W + 
 inline long wino4_pad(long tiles) { return (tiles + 127) / 128 * 128; }
 void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s);
 void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s);
+// pool: 0 none; 1 MaxPool 2x2/2 (y [B,H/2,W/2,Cout]); 2 MaxPool (2,2)/(2,1)/pad (0,1) (y [B,H/2,W+1,Cout])
 void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
                       int Cout, int act, int pool, hipStream_t s);
 

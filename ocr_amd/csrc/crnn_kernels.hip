@@ -886,6 +886,98 @@ __global__ __launch_bounds__(256) void wino4_out_kernel(const float* __restrict_
   }
 }
 
+// Output transform + MaxPool (2,2)/(2,1)/pad (0,1) (pool2 / pool3) in one kernel: the pool's windows cross tile
+// columns, so one thread owns a whole ROW of tiles for 4 channels and walks along x carrying the row-pair maxima of
+// the previous tile's last column; the full-resolution conv output is never written.  y: [B, H/2, W+1, Co].
+__global__ __launch_bounds__(256) void wino4_out_pool21_kernel(const float* __restrict__ Mo,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               const int32_t* __restrict__ wvalid, int B, int H, int W,
+                                                               int Co, int act, long ntile_pad, int nseg) {
+  const int th = H >> 2, tw = (W + 3) >> 2, C4 = Co >> 2, Wp = W + 1, Hp = H >> 1;
+  const int seglen = (tw + nseg - 1) / nseg;
+  const long total = (long)B * th * nseg * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int seg = (int)(r % nseg);
+    r /= nseg;
+    const int ty = (int)(r % th);
+    const int b = (int)(r / th);
+    // a row is cut into nseg segments; a segment after the first recomputes the tile before it for its last column
+    const int tx0 = seg * seglen, tx1 = tx0 + seglen < tw ? tx0 + seglen : tw;
+    const f32x4 bs = *(const f32x4*)(bias + c4 * 4);
+    const int wv = wvalid ? wvalid[b] : W;
+    float* yrow = y + ((long)b * Hp + 2 * ty) * Wp * Co + c4 * 4;
+    f32x4 prev[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // column 4 tx - 1, rows (0,1) and (2,3) of the tile row
+    for (int tx = tx0 > 0 ? tx0 - 1 : 0; tx < tx1; tx++) {
+      const bool emit = tx >= tx0;
+      const long t = ((long)b * th + ty) * tw + tx;
+      // all 36 loads first (few threads, each walking a row: the memory parallelism has to come from inside a thread)
+      f32x4 mm[6][6];
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+          mm[j][k] = __builtin_nontemporal_load((const f32x4*)(Mo + ((long)(k * 6 + j) * ntile_pad + t) * Co + c4 * 4));
+      f32x4 s[4][6];   // A^T m
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        f32x4 c[4];
+        wino4_at(mm[j], c);
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[k][j] = c[k];
+      }
+      f32x4 cm[2][4];   // max over the two rows of each pool window, per column of the tile
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        f32x4 o[4];
+        wino4_at(s[k], o);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int xx = 4 * tx + j;
+          f32x4 v = o[j] + bs;
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            float e = v[c];
+            if (act == 1) e = e > 0.f ? e : 0.f;
+            else if (act == 2) e = e > 0.f ? e : 0.2f * e;
+            if (xx >= wv) e = 0.f;
+            v[c] = e;
+          }
+          if (k & 1) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) cm[k >> 1][j][c] = fmaxf(cm[k >> 1][j][c], v[c]);
+          } else {
+            cm[k >> 1][j] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int pr = 0; pr < 2; pr++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int xx = 4 * tx + j;            // pooled column xx = max over conv columns xx - 1 and xx
+          if (xx > W || !emit) continue;
+          f32x4 v;
+          const f32x4 left = j == 0 ? prev[pr] : cm[pr][j - 1];
+          if (xx == W) v = left;                // right edge: column W - 1 alone
+          else if (xx == 0) v = cm[pr][0];      // left edge: column 0 alone
+          else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = fmaxf(left[c], cm[pr][j][c]);
+          }
+          *(f32x4*)(yrow + ((long)pr * Wp + xx) * Co) = v;
+        }
+      prev[0] = cm[0][3];
+      prev[1] = cm[1][3];
+    }
+    if ((W & 3) == 0 && tx1 == tw && tx0 < tw) {   // W a multiple of 4: the last pooled column lies past the last tile
+      *(f32x4*)(yrow + (long)W * Co) = prev[0];
+      *(f32x4*)(yrow + ((long)Wp + W) * Co) = prev[1];
+    }
+  }
+}
+
 // The 36 GEMMs M[c] = V[c] U[c]^T as ONE persistent launch.  Work unit = (component, 128 tiles, TBN channels),
 // K = Cin; unit u = (component * ntm + m-tile) * ntn + n-tile.  Block L takes units L, L + G, L + 2G, ...:
 // the launch is G = one block per CU slot, every block gets the same number of units (+-1) -- no partly filled
@@ -1490,6 +1582,13 @@ void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipSt
 }
 void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
                       int Cout, int act, int pool, hipStream_t s) {
+  if (pool == 2) {
+    const int tw = (W + 3) / 4, nseg = tw >= 16 ? tw / 8 : 1;   // segments of 8-9 tiles (one extra tile of work each)
+    const long rows = (long)B * (H / 4) * nseg * (Cout / 4);
+    hipLaunchKernelGGL(wino4_out_pool21_kernel, dim3(ew_blocks_w(rows)), dim3(256), 0, s, M, bias, y, wvalid, B, H, W,
+                       Cout, act, wino4_pad(wino4_tiles(B, H, W)), nseg);
+    return;
+  }
   const long total = wino4_tiles(B, H, W) * (Cout / 4);
   hipLaunchKernelGGL(wino4_out_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, M, bias, y, wvalid, B, H, W, Cout,
                      act, pool, wino4_pad(wino4_tiles(B, H, W)));

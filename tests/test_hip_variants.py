@@ -48,6 +48,7 @@ VARIANTS = [
     ({"CRNN_WINO4_SHAPE": "2"}, 1),                           # F(4x4) GEMM units of 128x64
     ({"CRNN_WINOGRAD_F4": "0x30", "CRNN_WINOGRAD": "0x08"}, 1),   # F(4x4) conv4-5, F(2x2) conv3, direct conv1-2
     ({"CRNN_WINO4_LW": "0"}, 1),                              # F(4x4) GEMM without the loader wave (every wave loads)
+    ({"CRNN_WINO4_POOL21": "0"}, 1),                          # pool2 / pool3 as separate kernels
     ({"CRNN_LIN_GEMM": "0"}, 1),                              # input projections / classifier on conv_gemm_kernel
 ]
 
@@ -57,7 +58,7 @@ VARIANTS = [
 def test_variant_strings_match_reference_goldens(env, lanes, golden):
     _, M = golden
     e = dict(os.environ)
-    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA", "CRNN_WINOGRAD_F4", "CRNN_WINO4_SHAPE", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_LW"):
+    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA", "CRNN_WINOGRAD_F4", "CRNN_WINO4_SHAPE", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_LW", "CRNN_WINO4_POOL21"):
         e.pop(k, None)
     e.update(env)
     code = CHILD % (ROOT, os.path.join(ROOT, "tests", "golden", "crnn_golden.npz"),
