@@ -80,6 +80,7 @@ struct crnn_handle {
   std::vector<float> h_wino4[7];
   unsigned wino4_mask = 0;
   int wino4_min_n = 1;
+  bool wino6 = true;      // conv6 as 1-D Winograd F(4,2) (fp32 path; CRNN_WINO6=0: implicit GEMM)
   bool lin_gemm = true;   // LSTM input projections and classifier on lin_gemm_kernel (CRNN_LIN_GEMM=0: conv_gemm_kernel)
   // recurrence: batches of up to split_max lines (8 workgroups per 16 lines: 192 of the 256 CUs at 384) use the
   // hidden-split latency kernel in the synchronous host paths (CRNN_LSTM_SPLIT=<max lines>, 0 = never)
@@ -333,7 +334,7 @@ struct Plan {
   size_t bytes;
 };
 
-static bool use_wino4(const crnn_handle* h, int n) { return h->wino4_mask && n >= h->wino4_min_n; }
+static bool use_wino4(const crnn_handle* h, int n) { return (h->wino4_mask || h->wino6) && n >= h->wino4_min_n; }
 
 Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
   Plan p{};
@@ -377,6 +378,11 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
         vmax = std::max(vmax, 16 * tl[i] * NM[i - 1]);
         if (!h->wino_fused) mmax = std::max(mmax, 16 * tl[i] * NM[i]);
       }
+    if (h->wino6 && use_wino4(h, (int)n)) {
+      const size_t tp = (size_t)wino4_pad((long)n * ((g.T + 3) / 4));
+      vmax = std::max(vmax, 5 * tp * 1024);
+      mmax = std::max(mmax, 5 * tp * 512);
+    }
     if (use_wino4(h, (int)n)) {
       const int hh[6] = {0, 16, 8, 8, 4, 4}, ww[6] = {0, g.W1, g.W2, g.W2, g.W3, g.W3};
       for (int i = 1; i <= 5; i++)
@@ -443,7 +449,7 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     launch_wino4_in((const float*)A, wino_v, n, Hin, Win, Cin, s);
     kmark(h, wn4[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 36.0 * tiles * Cin));
     Wino4Gemm w{};
-    w.V = wino_v; w.U = h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co; w.Cin = Cin;
+    w.V = wino_v; w.U = h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co; w.Cin = Cin; w.ncomp = 36;
     launch_wino4_gemm(w, s);
     kmark(h, wn4[1][layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * 36 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
     static const bool fuse21 = !(getenv("CRNN_WINO4_POOL21") && atoi(getenv("CRNN_WINO4_POOL21")) == 0);
@@ -456,6 +462,21 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     kmark(h, pool21_out ? (layer == 3 ? "conv3_wout4_pool2" : "conv5_wout4_pool3") : wn4[2][layer], 0,
           4.0 * (36.0 * tiles * Co + outpx * Co));
     return pool_out != nullptr || pool21_out != nullptr;
+  }
+  if (!b16 && layer == 6 && h->wino6 && wino_v && wino_m && use_wino4(h, n)) {
+    // conv6 as 1-D Winograd F(4,2) along the width: 5 GEMMs of K = 2 Cin instead of one of K = 4 Cin
+    const int Co = NM[6];
+    const long tiles = (long)n * ((Wout + 3) / 4), tp = wino4_pad(tiles);
+    hipStream_t s = tl_cur->stream;
+    launch_wino42_in((const float*)A, wino_v, n, Win, Cin, s);
+    kmark(h, "conv6_win4", 0, 4.0 * ((double)n * 2 * Win * Cin + 5.0 * tiles * 2 * Cin));
+    Wino4Gemm w{};
+    w.V = wino_v; w.U = h->d_wino4[6]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co; w.Cin = 2 * Cin; w.ncomp = 5;
+    launch_wino4_gemm(w, s);
+    kmark(h, "conv6_f4", 2.0 * 5 * tiles * Co * 2 * Cin, 4.0 * 5 * ((double)tiles * 2 * Cin + (double)Co * 2 * Cin + (double)tiles * Co));
+    launch_wino42_out(wino_m, h->d_conv_b[6], (float*)C, n, Wout, Co, h->cfg.leaky_relu ? 2 : 1, s);
+    kmark(h, "conv6_wout4", 0, 4.0 * (5.0 * tiles * Co + (double)n * Wout * Co));
+    return false;
   }
   if (!b16 && ((h->wino_mask >> layer) & 1u) && wino_v) {
     // Winograd F(2x2,3x3): input transform, 16 batched GEMMs (K = Cin), output transform
@@ -551,7 +572,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     else launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
     kmark(h, "pool3", 0, es * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
   }
-  conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T);
+  conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T, p.wv, p.wm);
   HIPCHK(h, hipEventRecord(tl_cur->ev[2], s));
   const int M = n * g.T;
   const double recflop = 2.0 * M * 2 * 1024 * 256;
@@ -741,13 +762,16 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   // Winograd layers (bit i = conv i, i in 1..5): default conv3..5 (measured best); CRNN_WINOGRAD=<mask> overrides (0 = off)
   h->wino_mask = cfg->precision == CRNN_FP32 ? 0x3Eu : 0u;
   if (const char* e = getenv("CRNN_WINO_FUSED")) h->wino_fused = atoi(e) != 0;
-  // F(4x4) layers (bit i = conv i): default conv1..5 (conv1, K = 64 per component and a product tensor twice the
-  // size of V, is equal to the fused F(2x2) form alone on the device but 2 % faster in the pipeline);
+  // F(4x4) layers (bit i = conv i): default conv2..5.  conv1 as F(4x4) is 2 % faster in the pipeline but its
+  // input (post-ReLU conv0 of raw pixels) has the widest dynamic range: on the noise line of the stage test the
+  // logit error grows from 4.6e-4 to 7.4e-4 of the 1e-3 bound, so it stays on the fused F(2x2) kernel.
   // CRNN_WINOGRAD_F4=<mask> overrides (0 = off), CRNN_WINO4_MIN_N=<lines>
-  h->wino4_mask = cfg->precision == CRNN_FP32 ? 0x3Eu : 0u;
+  h->wino4_mask = cfg->precision == CRNN_FP32 ? 0x3Cu : 0u;
   if (const char* e = getenv("CRNN_WINOGRAD_F4")) h->wino4_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
   if (const char* e = getenv("CRNN_WINO4_MIN_N")) h->wino4_min_n = atoi(e);
   if (const char* e = getenv("CRNN_LIN_GEMM")) h->lin_gemm = atoi(e) != 0;
+  if (const char* e = getenv("CRNN_WINO6")) h->wino6 = atoi(e) != 0;
+  if (cfg->precision != CRNN_FP32) h->wino6 = false;
   if (const char* e = getenv("CRNN_LSTM_SPLIT")) h->split_max = atoi(e);
   if (const char* e = getenv("CRNN_WINOGRAD")) h->wino_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
   for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);
@@ -874,6 +898,28 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
             h->h_wino4[i][((size_t)(a * 6 + b) * co + o) * cin + c] =
                 (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
       }
+    }
+  }
+  // conv6 as F(4,2) along the width: U6[b][o][ky * 512 + c] = sum_l G[b][l] w[o][c][ky][l]
+  if (h->wino6) {
+    const int cin = NM[5], co = NM[6];
+    const float* w = m["cnn.conv6.weight"]->data;
+    const float *g = nullptr, *var = nullptr;
+    if (HAS_BN[6]) {
+      g = m["cnn.batchnorm6.weight"]->data;
+      var = m["cnn.batchnorm6.running_var"]->data;
+    }
+    static const double G[5][2] = {{0.5, 0}, {-0.5, -0.5}, {-1.0 / 6, 1.0 / 6}, {1.0 / 6, 1.0 / 3}, {0, 1}};
+    h->h_wino4[6].assign((size_t)5 * co * 2 * cin, 0.f);
+    for (int o = 0; o < co; o++) {
+      const double sc = g ? (double)g[o] / std::sqrt((double)var[o] + 1e-5) : 1.0;
+      for (int c = 0; c < cin; c++)
+        for (int ky = 0; ky < 2; ky++) {
+          const double w0 = (double)w[(((size_t)o * cin + c) * 2 + ky) * 2 + 0] * sc;
+          const double w1 = (double)w[(((size_t)o * cin + c) * 2 + ky) * 2 + 1] * sc;
+          for (int b = 0; b < 5; b++)
+            h->h_wino4[6][((size_t)b * co + o) * 2 * cin + (size_t)ky * cin + c] = (float)(G[b][0] * w0 + G[b][1] * w1);
+        }
     }
   }
   if (h->cfg.lstm) {

@@ -176,10 +176,14 @@ struct Wino4Gemm {
   const float* U;   // [36][N][Cin]
   float* M;         // [36][ntile_pad][N]
   int ntile_pad, N, Cin;
+  int ncomp;        // number of component GEMMs: 36 (F(4x4,3x3)); 5 for conv6's 1-D F(4,2)
 };
 inline long wino4_tiles(int B, int H, int W) { return (long)B * (H / 4) * ((W + 3) / 4); }
 inline long wino4_pad(long tiles) { return (tiles + 127) / 128 * 128; }
 void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s);
+// conv6 as 1-D F(4,2): x NHWC [B,2,W,C] -> V[5][pad(B*ceil((W-1)/4))][2*C]; M[5][..][Cout] -> y [B*(W-1)][Cout] + bias, act
+void launch_wino42_in(const float* x, float* V, int B, int W, int C, hipStream_t s);
+void launch_wino42_out(const float* M, const float* bias, float* y, int B, int T, int Cout, int act, hipStream_t s);
 void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s);
 // pool: 0 none; 1 MaxPool 2x2/2 (y [B,H/2,W/2,Cout]); 2 MaxPool (2,2)/(2,1)/pad (0,1) (y [B,H/2,W+1,Cout])
 void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,

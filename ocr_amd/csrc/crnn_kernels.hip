@@ -993,7 +993,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino4_gemm_kernel
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
-  const int NU = 36 * ntm * ntn, G = gridDim.x;
+  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
   const int chunk = G >> 3;
   const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (L >= NU) return;
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(576, 1) void wino4_gemm_lw_kernel(const Wino4Gemm p
   __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];   // [B0 B1 B2 | A0 A1 A2]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
-  const int NU = 36 * ntm * ntn, G = gridDim.x;
+  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
   const int chunk = G >> 3;
   const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (L >= NU) return;
@@ -1567,7 +1567,7 @@ void launch_lin_gemm(const ConvGemm& p0, hipStream_t s) {
 void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
   static const int shape = getenv("CRNN_WINO4_SHAPE") ? atoi(getenv("CRNN_WINO4_SHAPE")) : 4;
   const int nwn = (shape == 2 || p.N % 128) ? 2 : 4;
-  const int units = 36 * (p.ntile_pad / 128) * (p.N / (32 * nwn));
+  const int units = p.ncomp * (p.ntile_pad / 128) * (p.N / (32 * nwn));
   const int slots = nwn == 2 ? 512 : 256;
   const int g = units < slots ? 8 * ((units + 7) / 8) : slots;
   static const int lw = getenv("CRNN_WINO4_LW") ? atoi(getenv("CRNN_WINO4_LW")) : 1;
@@ -1592,6 +1592,95 @@ void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t
   const long total = wino4_tiles(B, H, W) * (Cout / 4);
   hipLaunchKernelGGL(wino4_out_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, M, bias, y, wvalid, B, H, W, Cout,
                      act, pool, wino4_pad(wino4_tiles(B, H, W)));
+}
+
+// ---------------------------------------------------------------------------
+// conv6 (2x2, no padding, input height 2 -> output height 1) as 1-D Winograd F(4,2) along the width: 5 products
+// per 4 outputs instead of 8 (Cook-Toom, points 0, 1, -1, 2, inf; derived and checked numerically):
+//   B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1]
+//   G   = [1/2 0; -1/2 -1/2; -1/6 1/6; 1/6 1/3; 0 1]          A^T = [1 1 1 1 0; 0 1 -1 2 0; 0 1 1 4 0; 0 1 -1 8 1]
+// The two kernel rows are folded into K: V6[5][tiles][ky * C + c], U6[5][Cout][ky * C + c]; the 5 GEMMs run on
+// wino4_gemm_lw_kernel (ncomp = 5, K = 2 C).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino42_in_kernel(const float* __restrict__ x, float* __restrict__ V, int B,
+                                                        int W, int C, long ntile_pad) {
+  const int T = W - 1, tw = (T + 3) >> 2, C4 = C >> 2;
+  const long total = (long)B * tw * 2 * C4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int ky = (int)(r & 1);
+    r >>= 1;
+    const int tx = (int)(r % tw);
+    const int b = (int)(r / tw);
+    const float* px = x + (((long)b * 2 + ky) * W) * C + c4 * 4;
+    f32x4 d[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int xx = 4 * tx + j;
+      d[j] = xx < W ? *(const f32x4*)(px + (long)xx * C) : z;
+    }
+    const f32x4 d31 = d[3] - d[1];
+    f32x4 v[5];
+    v[0] = 2.f * (d[0] - d[2]) + d31;
+    v[1] = d[3] - d[2] - 2.f * d[1];
+    v[2] = 2.f * d[1] - 3.f * d[2] + d[3];
+    v[3] = d31;
+    v[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    const long t = (long)b * tw + tx;
+    float* o = V + (t * 2 + ky) * C + c4 * 4;
+#pragma unroll
+    for (int k = 0; k < 5; k++) *(f32x4*)(o + (long)k * ntile_pad * 2 * C) = v[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void wino42_out_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int B, int T, int Co, int act,
+                                                         long ntile_pad) {
+  const int tw = (T + 3) >> 2, C4 = Co >> 2;
+  const long total = (long)B * tw * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const int b = (int)(t / tw);
+    f32x4 m[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) m[k] = *(const f32x4*)(Mo + ((long)k * ntile_pad + t) * Co + c4 * 4);
+    const f32x4 bs = *(const f32x4*)(bias + c4 * 4);
+    const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2];
+    f32x4 o[4];
+    o[0] = m[0] + s12 + m[3];
+    o[1] = d12 + 2.f * m[3];
+    o[2] = s12 + 4.f * m[3];
+    o[3] = d12 + 8.f * m[3] + m[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int xx = 4 * tx + j;
+      if (xx >= T) continue;
+      f32x4 v = o[j] + bs;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        float e = v[c];
+        if (act == 1) e = e > 0.f ? e : 0.f;
+        else if (act == 2) e = e > 0.f ? e : 0.2f * e;
+        v[c] = e;
+      }
+      *(f32x4*)(y + ((long)b * T + xx) * Co + c4 * 4) = v;
+    }
+  }
+}
+
+void launch_wino42_in(const float* x, float* V, int B, int W, int C, hipStream_t s) {
+  const long tiles = (long)B * ((W - 1 + 3) / 4);
+  hipLaunchKernelGGL(wino42_in_kernel, dim3(ew_blocks_w(tiles * 2 * (C / 4))), dim3(256), 0, s, x, V, B, W, C,
+                     wino4_pad(tiles));
+}
+void launch_wino42_out(const float* M, const float* bias, float* y, int B, int T, int Cout, int act, hipStream_t s) {
+  const long tiles = (long)B * ((T + 3) / 4);
+  hipLaunchKernelGGL(wino42_out_kernel, dim3(ew_blocks_w(tiles * (Cout / 4))), dim3(256), 0, s, M, bias, y, B, T, Cout,
+                     act, wino4_pad(tiles));
 }
 
 // ---------------------------------------------------------------------------

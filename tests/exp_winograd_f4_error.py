@@ -62,10 +62,38 @@ class WinoConv(nn.Module):
         return y + self.bias[None, :, None, None]
 
 
+class WinoConv6(nn.Module):
+    """conv6 (2x2, no padding, input height 2 -> output height 1) as 1-D F(4,2) along the width, fp32."""
+    BT = torch.tensor([[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]],
+                      dtype=torch.float64)
+    G = torch.tensor([[.5, 0], [-.5, -.5], [-1 / 6, 1 / 6], [1 / 6, 1 / 3], [0, 1]], dtype=torch.float64)
+    AT = torch.tensor([[1, 1, 1, 1, 0], [0, 1, -1, 2, 0], [0, 1, 1, 4, 0], [0, 1, -1, 8, 1]], dtype=torch.float64)
+
+    def __init__(self, conv):
+        super().__init__()
+        w = conv.weight.detach().double()                       # [O, I, 2, 2]
+        self.U = torch.einsum("bl,oikl->bkoi", self.G, w).float().contiguous()   # [5, ky, O, I]
+        self.bias = conv.bias.detach()
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        wo = w - 1
+        tw = -(-wo // 4)
+        xp = F.pad(x, (0, tw * 4 + 1 - w))
+        p = xp.unfold(3, 5, 4)                                  # [n, c, 2, tw, 5]
+        v = torch.einsum("bl,nckxl->bknxc", self.BT.float(), p)   # [5, ky, n, tw, c]
+        m = torch.einsum("bknxc,bkoc->bnxo", v, self.U)          # sum over ky and c
+        y = torch.einsum("jb,bnxo->noxj", self.AT.float(), m).reshape(n, -1, 1, tw * 4)[..., :wo]
+        return y + self.bias[None, :, None, None]
+
+
 def build(nclass, sd, layers, mh, mw):
     m = TorchPort(nclass).load_numpy(sd)
     for i in layers:
-        setattr(m.cnn, "conv%d" % i, WinoConv(getattr(m.cnn, "conv%d" % i), mh, mw))
+        if i == 6:
+            m.cnn.conv6 = WinoConv6(m.cnn.conv6)
+        else:
+            setattr(m.cnn, "conv%d" % i, WinoConv(getattr(m.cnn, "conv%d" % i), mh, mw))
     return m
 
 
@@ -81,7 +109,8 @@ def main():
     cases = [("var/%d" % w, G["var/%d/gray" % w], G["var/%d/en_logits" % w]) for w in M["var_widths"]]
     variants = [("direct", [], 2, 2), ("F2x2 c1-5", [1, 2, 3, 4, 5], 2, 2), ("F2x4 c1-5", [1, 2, 3, 4, 5], 2, 4),
                 ("F4x4 c1-5", [1, 2, 3, 4, 5], 4, 4), ("F4x4 c2-5", [2, 3, 4, 5], 4, 4),
-                ("F4x4 c4-5", [4, 5], 4, 4), ("F4x4 c1", [1], 4, 4)]
+                ("F4x4 c4-5", [4, 5], 4, 4), ("F4x4 c1", [1], 4, 4), ("F(4,2) c6", [6], 4, 4),
+                ("F4x4 c1-5 + F(4,2) c6", [1, 2, 3, 4, 5, 6], 4, 4)]
     torch.set_num_threads(8)
     for name, layers, mh, mw in variants:
         net = build(65, sd, layers, mh, mw)

@@ -42,13 +42,14 @@ VARIANTS = [
     ({**F2, "CRNN_WINO_DMA": "3"}, 1),                        # 64x64 tiles
     (F2, 4),                                                  # F(2x2) per-launch tile choice, lanes sharing the device
     ({**F2, "CRNN_WINOGRAD": "0x38"}, 2),                     # F(2x2) on conv3-5 only
-    ({}, 1),                                                  # default: F(4x4) on conv1-5 (pool1 in conv1's output transform)
+    ({}, 1),                                                  # default: F(4x4) on conv2-5, fused F(2x2) on conv1, F(4,2) on conv6
     ({}, 4),
-    ({"CRNN_WINOGRAD_F4": "0x3C"}, 2),                        # conv1 on the fused F(2x2) kernel
+    ({"CRNN_WINOGRAD_F4": "0x3E"}, 2),                        # F(4x4) on conv1 too (pool1 in its output transform)
     ({"CRNN_WINO4_SHAPE": "2"}, 1),                           # F(4x4) GEMM units of 128x64
     ({"CRNN_WINOGRAD_F4": "0x30", "CRNN_WINOGRAD": "0x08"}, 1),   # F(4x4) conv4-5, F(2x2) conv3, direct conv1-2
     ({"CRNN_WINO4_LW": "0"}, 1),                              # F(4x4) GEMM without the loader wave (every wave loads)
     ({"CRNN_WINO4_POOL21": "0"}, 1),                          # pool2 / pool3 as separate kernels
+    ({"CRNN_WINO6": "0"}, 1),                                 # conv6 as implicit GEMM instead of 1-D F(4,2)
     ({"CRNN_LIN_GEMM": "0"}, 1),                              # input projections / classifier on conv_gemm_kernel
 ]
 
@@ -58,7 +59,7 @@ VARIANTS = [
 def test_variant_strings_match_reference_goldens(env, lanes, golden):
     _, M = golden
     e = dict(os.environ)
-    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA", "CRNN_WINOGRAD_F4", "CRNN_WINO4_SHAPE", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_LW", "CRNN_WINO4_POOL21"):
+    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA", "CRNN_WINOGRAD_F4", "CRNN_WINO4_SHAPE", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_LW", "CRNN_WINO4_POOL21", "CRNN_WINO6"):
         e.pop(k, None)
     e.update(env)
     code = CHILD % (ROOT, os.path.join(ROOT, "tests", "golden", "crnn_golden.npz"),
