@@ -205,8 +205,8 @@ def main():
     value = lines_total / elapsed
     gemm_names = [n for n in order if (n.startswith("conv") and n != "conv0_pool0" and "_win" not in n and "_wout" not in n)
                   or n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
-    # GEMM kernels of the fp32 path: conv1-5 run as Winograd F(4x4) ("<layer>_f4": wino4_gemm_lw_kernel; a layer
-    # switched back to fused F(2x2) has a "<layer>_win" launch before it: wino_gemm_dma_kernel), the LSTM input projections and the
+    # GEMM kernels of the fp32 path: conv2-5 run as Winograd F(4x4) and conv6 as 1-D F(4,2) ("<layer>_f4":
+    # wino4_gemm_lw_kernel), conv1 as fused F(2x2) (a "<layer>_win" launch before it: wino_gemm_dma_kernel), the LSTM input projections and the
     # classifier on lin_gemm_kernel (same persistent direct-to-LDS pipeline as wino4_gemm_kernel), conv6 and the
     # embedding on conv_gemm_kernel.  The roofline object is for whichever kernel takes most of the step
     # (rocprof's per-kernel average is over the same launches).
@@ -233,13 +233,12 @@ def main():
                            "the 128x128-tile launch over the full rounds plus the small-tile launch over the remaining tiles"))
     if wino4_names:
         fams.append(family("wino4_gemm_lw_kernel", wino4_names,
-                           "Winograd F(4x4,3x3): the 36 component GEMMs of a layer as one persistent launch of 128x128 "
-                           "units, executed MFMA FLOPs"))
+                           "Winograd component GEMMs of a layer -- 36 for F(4x4,3x3) on conv2-5, 5 for conv6's 1-D F(4,2) -- "
+                           "as one persistent launch of 128x128 units, executed MFMA FLOPs"))
     if lin_names:
         fams.append(family("lin_gemm_kernel", lin_names, "LSTM input projections + classifier with fused arg-max, "
                            "persistent launch of 128x128 units"))
-    fams.append(family(direct_kernel, direct_names, "implicit-GEMM conv6 + embedding" if lin_names else
-                       "implicit-GEMM conv + LSTM input projections + embedding + classifier"))
+    fams.append(family(direct_kernel, direct_names, "implicit GEMM: " + ", ".join(direct_names)))
     fams.sort(key=lambda f: -f["ms_per_step"])
     dom = fams[0]
     gemm_names = dom["launches"]
