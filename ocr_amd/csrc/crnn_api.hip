@@ -80,6 +80,10 @@ struct crnn_handle {
   std::vector<float> h_wino4[7];
   unsigned wino4_mask = 0;
   int wino4_min_n = 1;
+  // classifier arg-max through the certified bf16 pre-filter when the logits are not requested (fp32 path;
+  // CRNN_CLS_FILTER=0: plain fp32 GEMM with the fused arg-max)
+  bool cls_filter = true;
+  std::vector<float> h_cls_wnorm;   // ||w_c|| of the classifier rows (rounded up)
   bool wino6 = true;      // conv6 as 1-D Winograd F(4,2) (fp32 path; CRNN_WINO6=0: implicit GEMM)
   bool lin_gemm = true;   // LSTM input projections and classifier on lin_gemm_kernel (CRNN_LIN_GEMM=0: conv_gemm_kernel)
   // recurrence: batches of up to split_max lines (8 workgroups per 16 lines: 192 of the 256 CUs at 384) use the
@@ -108,6 +112,7 @@ struct crnn_handle {
   float* d_lin_b = nullptr;
   float* d_wino[7] = {};
   float* d_wino4[7] = {};
+  float* d_cls_wnorm = nullptr;
   float* d_zero_bias = nullptr;   // 512 zeros: the Winograd GEMMs add the bias in the output transform
   uint16_t* db_conv_w[7] = {};
   uint16_t* db_wih[2] = {};
@@ -252,6 +257,7 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       if ((rc = upload(h, h->h_wino[i], &h->d_wino[i]))) return rc;
     for (int i = 0; i < 7; i++)
       if ((rc = upload(h, h->h_wino4[i], &h->d_wino4[i]))) return rc;
+    if ((rc = upload(h, h->h_cls_wnorm, &h->d_cls_wnorm))) return rc;
     for (int l = 0; l < 2; l++) {
       if ((rc = upload16(h, h->hb_wih[l], &h->db_wih[l]))) return rc;
       if ((rc = upload16(h, h->hb_whhp[l], &h->db_whhp[l]))) return rc;
@@ -328,6 +334,8 @@ struct Plan {
   float *x, *p0, *c1, *p1, *c2, *c3, *p2, *c4, *c5, *p3, *seq, *xp, *rec0, *mid, *rec1, *logits;
   int32_t *wl;   // [8][n] per-layer width arrays
   int32_t *raw;  // [n*T]
+  uint16_t* a16;  // [n*T][512] bf16 copy of the classifier's input (certified pre-filter)
+  float* anorm;   // [n*T] its row norms
   float* pmax;   // [n*T][n-tiles of the classifier]
   float *wv, *wm; // Winograd V[16][tiles][Cin] and Mo[16][tiles][Cout] (largest enabled layer)
   int32_t* pidx;
@@ -361,6 +369,8 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
   p.mid = take(n * g.T * 256);
   p.rec1 = take(n * g.T * 512);
   p.logits = take(n * g.T * (size_t)h->cfg.nclass);
+  p.a16 = (uint16_t*)take(n * g.T * 256);   // 512 bf16 per row
+  p.anorm = take(n * g.T);
   p.wl = (int32_t*)take(8 * n);
   p.raw = (int32_t*)take(n * g.T);
   const size_t ntn = 4 * (((size_t)h->cfg.nclass + 127) / 128);   // lin_gemm_kernel: one partial per 32 columns
@@ -598,17 +608,38 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     else launch_lstm_rec(p.xp, h->d_whhp[l], out, tlen, n, g.T, s);
     kmark(h, l ? "lstm1_rec" : "lstm0_rec", recflop, recbytes);
   };
+  // classifier + arg-max.  Logits not requested (every product path): certified bf16 pre-filter + exact fp32
+  // scoring of the candidates (crnn_kernels.hip); plan.logits is the filter's scratch.  Otherwise the fp32 GEMM
+  // with the fused arg-max partials.
+  bool filtered = false;
+  auto classify = [&](const float* in, const float* Wf, const uint16_t* W16, const float* bias) {
+    const int N = h->cfg.nclass;
+    if (!b16 && h->cls_filter && !want_logits && N >= 512 && h->d_cls_wnorm && W16) {
+      launch_rows_to_bf16(in, p.a16, p.anorm, M, 512, s);
+      kmark(h, "cls_to_bf16", 0, 6.0 * M * 512);
+      ConvGemm q{};
+      q.A = (const float*)p.a16; q.Wt = (const float*)W16; q.bias = bias; q.C = p.logits;
+      q.M = M; q.N = N; q.K = 512; q.ldc = N;
+      q.Hin = q.Win = q.Hout = q.Wout = 1; q.Cin = 512; q.ks = 1; q.pad = 0; q.act = 0;
+      launch_conv_gemm_bf16(q, false, s);
+      // bf16 MFMA work: not counted with the f32 MFMA FLOPs (bench.py's executed-FLOP rate is against the f32 peak)
+      kmark(h, "cls_filter_bf16", 0, 2.0 * ((double)M * 512 + (double)N * 512) + 4.0 * M * N);
+      launch_cls_select(p.logits, in, Wf, bias, p.anorm, h->d_cls_wnorm, p.raw, M, N, 512, s);
+      kmark(h, "cls_select", 0, 8.0 * M * N);
+      return true;
+    }
+    gemm(h, "classifier", in, Wf, W16, bias, want_logits ? p.logits : nullptr, M, N, 512, false, p.pmax, p.pidx);
+    return false;
+  };
   if (h->cfg.lstm) {
     gemm(h, "lstm0_ih", p.seq, h->d_wih[0], h->db_wih[0], h->d_bih[0], p.xp, M, 2048, 512, false);
     rec(0, p.rec0);
     gemm(h, "emb0", p.rec0, h->d_emb_w[0], h->db_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512, true);
     gemm(h, "lstm1_ih", p.mid, h->d_wih[1], h->db_wih[1], h->d_bih[1], p.xp, M, 2048, 256, false);
     rec(1, p.rec1);
-    gemm(h, "classifier", p.rec1, h->d_emb_w[1], h->db_emb_w[1], h->d_emb_b[1], want_logits ? p.logits : nullptr, M,
-         h->cfg.nclass, 512, false, p.pmax, p.pidx);
+    filtered = classify(p.rec1, h->d_emb_w[1], h->db_emb_w[1], h->d_emb_b[1]);
   } else {
-    gemm(h, "classifier", p.seq, h->d_lin_w, h->db_lin_w, h->d_lin_b, want_logits ? p.logits : nullptr, M,
-         h->cfg.nclass, 512, false, p.pmax, p.pidx);
+    filtered = classify(p.seq, h->d_lin_w, h->db_lin_w, h->d_lin_b);
   }
   HIPCHK(h, hipEventRecord(tl_cur->ev[3], s));
   // the classifier's epilogue left per-tile (max, index) partials: finish the arg-max over tiles
@@ -619,8 +650,10 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     q.M = M; q.N = h->cfg.nclass; q.K = 512; q.ks = 1;
     if (!b16 && use_lin_gemm(h, q)) ntn *= 4;
   }
-  launch_argmax_partials(p.pmax, p.pidx, p.raw, M, ntn, s);
-  kmark(h, "argmax", 0, 8.0 * M * ntn + 4.0 * M);
+  if (!filtered) {
+    launch_argmax_partials(p.pmax, p.pidx, p.raw, M, ntn, s);
+    kmark(h, "argmax", 0, 8.0 * M * ntn + 4.0 * M);
+  }
   launch_ctc(p.raw, tlen, d_lab, d_len, n, g.T, s);
   kmark(h, "ctc", 0, 4.0 * (2.0 * M + n));
   HIPCHK(h, hipEventRecord(tl_cur->ev[4], s));
@@ -771,6 +804,8 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   if (const char* e = getenv("CRNN_WINO4_MIN_N")) h->wino4_min_n = atoi(e);
   if (const char* e = getenv("CRNN_LIN_GEMM")) h->lin_gemm = atoi(e) != 0;
   if (const char* e = getenv("CRNN_WINO6")) h->wino6 = atoi(e) != 0;
+  if (const char* e = getenv("CRNN_CLS_FILTER")) h->cls_filter = atoi(e) != 0;
+  if (cfg->precision != CRNN_FP32) h->cls_filter = false;
   if (cfg->precision != CRNN_FP32) h->wino6 = false;
   if (const char* e = getenv("CRNN_LSTM_SPLIT")) h->split_max = atoi(e);
   if (const char* e = getenv("CRNN_WINOGRAD")) h->wino_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
@@ -956,6 +991,19 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
     if (!lb) return fail(h, CRNN_ERR_ARG, err);
     h->h_lin_w.assign(lw, lw + (size_t)nclass * 2 * nh);
     h->h_lin_b.assign(lb, lb + nclass);
+  }
+  if (h->cls_filter) {
+    const std::vector<float>& wsrc = h->cfg.lstm ? h->h_emb_w[1] : h->h_lin_w;
+    std::vector<uint16_t>& wdst = h->cfg.lstm ? h->hb_emb_w[1] : h->hb_lin_w;
+    const int kk = 2 * nh;
+    wdst.resize(wsrc.size());
+    for (size_t i = 0; i < wsrc.size(); i++) wdst[i] = f32_to_bf16_host(wsrc[i]);
+    h->h_cls_wnorm.assign(nclass, 0.f);
+    for (int c = 0; c < nclass; c++) {
+      double ss = 0;
+      for (int k = 0; k < kk; k++) ss += (double)wsrc[(size_t)c * kk + k] * wsrc[(size_t)c * kk + k];
+      h->h_cls_wnorm[c] = (float)(std::sqrt(ss) * 1.000001);
+    }
   }
   if (h->cfg.precision == CRNN_BF16) {
     auto cvt = [](const std::vector<float>& src, std::vector<uint16_t>& dst) {
@@ -1335,6 +1383,7 @@ void crnn_destroy(crnn_handle* h) {
     (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->db_lin_w); (void)hipFree(h->d_zero_bias);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4[i]);
+    (void)hipFree(h->d_cls_wnorm);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }
     if (h->split_ev) (void)hipEventDestroy(h->split_ev);

@@ -2183,6 +2183,155 @@ void launch_argmax_partials(const float* pmax, const int32_t* pidx, int32_t* idx
   hipLaunchKernelGGL(argmax_partials_kernel, dim3((M + 3) / 4), dim3(256), 0, s, pmax, pidx, idx, M, ntiles);
 }
 
+// ---------------------------------------------------------------------------
+// Certified bf16 pre-filter for the classifier's arg-max (fp32 path, logits not requested).
+// The arg-max over 5530 classes needs every logit only to know which one is largest, and the bf16 MFMA is 16x
+// faster than the f32 one.  So: (1) the activations are rounded to bf16 (RNE) and their row norms ||a|| taken;
+// (2) the bf16 GEMM writes approximate logits l~ (fp32 accumulate, exact bf16 x bf16 products); (3) per row, with
+// the rigorous bound |l~_c - l_c| <= e_c = (2u + u^2) ||a|| ||w_c||  (u = 2^-8, Cauchy-Schwarz over the per-term
+// rounding errors, plus slack for the fp32 accumulation), every class whose upper bound l~_c + e_c reaches the best
+// lower bound max_c (l~_c - e_c) is a candidate -- the true arg-max is certainly among them -- and (4) the
+// candidates (usually one, then nothing is left to do) are scored exactly: fp32 dot products of the fp32
+// activations and weights, ties to the lowest index.  The decision is therefore made in fp32; bf16 only prunes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ A, uint16_t* __restrict__ out,
+                                                           float* __restrict__ norm, int M, int K) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* a = A + (long)row * K;
+  float ss = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const f32x4 v = *(const f32x4*)(a + k);
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    union { __bf16 h[4]; uint2 u; } pk;
+#pragma unroll
+    for (int e = 0; e < 4; e++) pk.h[e] = (__bf16)v[e];
+    *(uint2*)(out + (long)row * K + k) = pk.u;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  if (lane == 0) norm[row] = sqrtf(ss) * 1.000001f;
+}
+
+__global__ __launch_bounds__(256) void cls_select_kernel(const float* __restrict__ L, const float* __restrict__ A,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         const float* __restrict__ anorm,
+                                                         const float* __restrict__ wnorm, int32_t* __restrict__ idx,
+                                                         int M, int N, int K) {
+  // one wave per row; the row is walked in chunks of 8 x 64 classes whose loads are issued together (a plain
+  // strided loop would pay the L2 latency once per 64 classes)
+  constexpr int U = 8;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* l = L + (long)row * N;
+  // (2u + u^2) with u = 2^-8 is 0.0078278; 0.00785 leaves room for the fp32 accumulation of 512 terms
+  const float an = anorm[row] * 0.00785f;
+  float lb = -INFINITY;
+  for (int c0 = 0; c0 < N; c0 += 64 * U) {
+    float lv[U], wn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int c = c0 + u * 64 + lane;
+      lv[u] = c < N ? l[c] : -INFINITY;
+      wn[u] = c < N ? wnorm[c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) lb = fmaxf(lb, lv[u] - an * wn[u]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) lb = fmaxf(lb, __shfl_xor(lb, off));
+  // candidate list (wave-uniform), the first 64 kept in LDS
+  __shared__ int cand_s[4][64];
+  int* cand = cand_s[threadIdx.x >> 6];
+  int count = 0;
+  for (int c0 = 0; c0 < N; c0 += 64 * U) {
+    float lv[U], wn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int c = c0 + u * 64 + lane;
+      lv[u] = c < N ? l[c] : -INFINITY;
+      wn[u] = c < N ? wnorm[c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      unsigned long long m = __ballot(lv[u] + an * wn[u] >= lb);   // -inf (past N) never qualifies
+      while (m) {
+        if (count < 64 && lane == 0) cand[count] = c0 + u * 64 + __builtin_ctzll(m);
+        count++;
+        m &= m - 1;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // lane 0's list entries before the other lanes read them
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (count <= 1) {   // the bound already separates the best class from all others
+    if (lane == 0) idx[row] = count == 1 ? cand[0] : 0;
+    return;
+  }
+  // several candidates: exact fp32 scores, ties to the lowest index.  The weight rows of up to eight candidates
+  // are fetched together (the fetch latency, not the arithmetic, is what a candidate costs).
+  const float* a = A + (long)row * K;
+  float best = -INFINITY;
+  int bi = 0x7FFFFFFF;
+  auto consider = [&](float part, int cc) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    const float v = part + bias[cc];
+    if (v > best || (v == best && cc < bi)) { best = v; bi = cc; }
+  };
+  if (K == 512 && count <= 64) {
+    const f32x4 a0 = *(const f32x4*)(a + lane * 4), a1 = *(const f32x4*)(a + 256 + lane * 4);
+    for (int base = 0; base < count; base += 8) {
+      f32x4 w0[8], w1[8];
+      int cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        cc[u] = base + u < count ? cand[base + u] : -1;
+        const float* w = W + (long)(cc[u] < 0 ? 0 : cc[u]) * K + lane * 4;
+        w0[u] = *(const f32x4*)w;
+        w1[u] = *(const f32x4*)(w + 256);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (cc[u] < 0) continue;
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) part = __builtin_fmaf(a0[e], w0[u][e], part);
+#pragma unroll
+        for (int e = 0; e < 4; e++) part = __builtin_fmaf(a1[e], w1[u][e], part);
+        consider(part, cc[u]);
+      }
+    }
+  } else {   // general K, or more candidates than the list holds: walk the row again, one candidate at a time
+    for (int c0 = 0; c0 < N; c0 += 64) {
+      const int c = c0 + lane;
+      unsigned long long m = __ballot(c < N && l[c] + an * wnorm[c] >= lb);
+      while (m) {
+        const int cc = c0 + __builtin_ctzll(m);
+        m &= m - 1;
+        const float* w = W + (long)cc * K;
+        float part = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+          const f32x4 av = *(const f32x4*)(a + k), wv = *(const f32x4*)(w + k);
+#pragma unroll
+          for (int e = 0; e < 4; e++) part = __builtin_fmaf(av[e], wv[e], part);
+        }
+        consider(part, cc);
+      }
+    }
+  }
+  if (lane == 0) idx[row] = bi == 0x7FFFFFFF ? 0 : bi;
+}
+
+void launch_rows_to_bf16(const float* A, uint16_t* out, float* norm, int M, int K, hipStream_t s) {
+  hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((M + 3) / 4), dim3(256), 0, s, A, out, norm, M, K);
+}
+void launch_cls_select(const float* L, const float* A, const float* W, const float* bias, const float* anorm,
+                       const float* wnorm, int32_t* idx, int M, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(cls_select_kernel, dim3((M + 3) / 4), dim3(256), 0, s, L, A, W, bias, anorm, wnorm, idx, M, N, K);
+}
+
 void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld, hipStream_t s) {
   hipLaunchKernelGGL(argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, idx, M, nclass, ld);
 }

@@ -294,3 +294,44 @@ def test_split_recurrences_of_concurrent_callers(golden, synth_en):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.gpu
+def test_classifier_prefilter_certificate(golden, synth_zh):
+    """The bf16 pre-filter of the classifier's arg-max (cls_select_kernel) rests on |l_bf16 - l| <= 0.00785 |a| |w_c|:
+    checked here on the GPU's own classifier input (stage 9) in float64, together with its consequence -- the true
+    arg-max is always among the candidates -- and the product path's indices (filter on) against the exact ones."""
+    from oracle import oracle as O
+    from ocr_amd.crnn.network_hip import CRNN
+    G, _ = golden
+
+    def to_bf16(x):
+        u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16          # round to nearest even
+        return u.astype(np.uint32).view(np.float32)
+
+    m = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0)
+    m.load_state_dict(synth_zh)
+    W = np.asarray(synth_zh["rnn.1.embedding.weight"], np.float32)
+    b = np.asarray(synth_zh["rnn.1.embedding.bias"], np.float32)
+    wn = np.sqrt((W.astype(np.float64) ** 2).sum(1))
+    for tag in ("noise", "text"):
+        lines = G["syn280/%s/gray" % tag]
+        x = np.stack([O.resize_normalize(g) for g in lines])
+        a = m.debug_stage(x, 9).reshape(-1, 512)
+        an = np.sqrt((a.astype(np.float64) ** 2).sum(1))
+        exact = a.astype(np.float64) @ W.astype(np.float64).T + b
+        approx = to_bf16(a).astype(np.float64) @ to_bf16(W).astype(np.float64).T + b
+        eps = 0.00785 * an[:, None] * wn[None, :]
+        assert (np.abs(approx - exact) <= eps).all()
+        lb = (approx - eps).max(1)
+        cand = approx + eps >= lb[:, None]
+        assert cand[np.arange(len(a)), exact.argmax(1)].all()
+        assert cand.sum(1).max() < 64          # the kernel's fast path covers these rows
+        # product path (filter on) == exact arg-max wherever the top two are not within fp32 rounding of each other
+        from ocr_amd.crnn import _capi
+        raw = m._run(list(lines), _capi.PAD_PER_LINE, want_raw=True)[3]     # logits not requested: filter path
+        top2 = np.sort(exact, 1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+        assert clear.mean() > 0.9
+        assert (raw.reshape(-1)[clear] == exact.argmax(1)[clear]).all()
