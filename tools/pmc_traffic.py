@@ -28,7 +28,8 @@ for _l in (2, 3, 4, 5):
     ORDER_F4 += ["conv%d_win4" % _l, "conv%d_f4" % _l,
                  "conv%d_wout4" % _l + {3: "_pool2", 5: "_pool3"}.get(_l, "")]
 ORDER_F4 += ["conv6_win4", "conv6_f4", "conv6_wout4",   # conv6 as 1-D F(4,2)
-              "lstm0_ih", "lstm0_rec", "emb0", "lstm1_ih", "lstm1_rec", "classifier", "argmax", "ctc"]
+              "lstm0_ih", "lstm0_rec", "emb0", "lstm1_ih", "lstm1_rec",
+              "cls_to_bf16", "cls_filter_bf16", "cls_select", "ctc"]   # classifier: certified bf16 pre-filter
 MODE = sys.argv[4] if len(sys.argv) > 4 else "direct"
 ORDER = {"wino": ORDER_WINO, "fused": ORDER_FUSED, "hybrid": ORDER_HYBRID, "f4": ORDER_F4}.get(MODE, ORDER_DIRECT)
 
