@@ -16,6 +16,7 @@ no data-path collective; gloo is used only for the barrier and the max over rank
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -205,7 +206,9 @@ def main():
     plain = None
     if (args.precision == "fp32" and world == 1 and not args.serial
             and os.environ.get("CRNN_CLS_FILTER", "1") != "0" and not args.no_cpu_baseline):
-        del run
+        # pinned result buffers remember the lane streams they were used on: free them (the closure) before the handle
+        run = None
+        gc.collect()
         model.__del__()          # frees the first handle's streams: both handles' lanes would share the hardware queues
         os.environ["CRNN_CLS_FILTER"] = "0"
         model2 = CRNN(32, 1, NCLASS, 256, leakyRelu=False, lstmFlag=True, GPU=True, alphabet=keys.alphabetChinese,
@@ -223,8 +226,12 @@ def main():
         plain = {"value": round(BATCH * args.steps / e2, 1), "unit": "text-lines/s",
                  "ms_per_step": round(e2 / args.steps * 1e3, 3),
                  "strings_identical_to_headline_path": "%d/%d" % (sum(a == b for a, b in zip(first_texts, texts2)), len(texts2))}
+        run2 = None
+        gc.collect()
         del model2
 
+    run = None          # same order at every exit: pinned buffers (held by the closure) go before the handle's streams
+    gc.collect()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -266,8 +273,8 @@ def main():
                            "Winograd component GEMMs of a layer -- 36 for F(4x4,3x3) on conv2-5, 5 for conv6's 1-D F(4,2) -- "
                            "as one persistent launch of 128x128 units, executed MFMA FLOPs"))
     if lin_names:
-        fams.append(family("lin_gemm_kernel", lin_names, "LSTM input projections + classifier with fused arg-max, "
-                           "persistent launch of 128x128 units"))
+        fams.append(family("lin_gemm_kernel", lin_names, "plain GEMMs as persistent launches of 128x128 units: " +
+                           ", ".join(lin_names)))
     fams.append(family(direct_kernel, direct_names, "implicit GEMM: " + ", ".join(direct_names)))
     fams.sort(key=lambda f: -f["ms_per_step"])
     dom = fams[0]
