@@ -614,18 +614,19 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   bool filtered = false;
   auto classify = [&](const float* in, const float* Wf, const uint16_t* W16, const float* bias) {
     const int N = h->cfg.nclass;
-    if (!b16 && h->cls_filter && !want_logits && N >= 512 && h->d_cls_wnorm && W16) {
+    if (!b16 && h->cls_filter && !want_logits && N >= 512 && N <= 8192 && h->d_cls_wnorm && W16) {
+      const int ldl = (N + 7) & ~7;   // bf16 rows of the approximate logits: 16-byte aligned
       launch_rows_to_bf16(in, p.a16, p.anorm, M, 512, s);
       kmark(h, "cls_to_bf16", 0, 6.0 * M * 512);
       ConvGemm q{};
       q.A = (const float*)p.a16; q.Wt = (const float*)W16; q.bias = bias; q.C = p.logits;
-      q.M = M; q.N = N; q.K = 512; q.ldc = N;
+      q.M = M; q.N = N; q.K = 512; q.ldc = ldl;
       q.Hin = q.Win = q.Hout = q.Wout = 1; q.Cin = 512; q.ks = 1; q.pad = 0; q.act = 0;
-      launch_conv_gemm_bf16(q, false, s);
+      launch_conv_gemm_bf16(q, true, s);    // approximate logits stored as bf16 in plan.logits
       // bf16 MFMA work: not counted with the f32 MFMA FLOPs (bench.py's executed-FLOP rate is against the f32 peak)
-      kmark(h, "cls_filter_bf16", 0, 2.0 * ((double)M * 512 + (double)N * 512) + 4.0 * M * N);
-      launch_cls_select(p.logits, in, Wf, bias, p.anorm, h->d_cls_wnorm, p.raw, M, N, 512, s);
-      kmark(h, "cls_select", 0, 8.0 * M * N);
+      kmark(h, "cls_filter_bf16", 0, 2.0 * ((double)M * 512 + (double)N * 512) + 2.0 * M * N);
+      launch_cls_select((const uint16_t*)p.logits, in, Wf, bias, p.anorm, h->d_cls_wnorm, p.raw, M, N, 512, ldl, s);
+      kmark(h, "cls_select", 0, 2.0 * M * N);
       return true;
     }
     gemm(h, "classifier", in, Wf, W16, bias, want_logits ? p.logits : nullptr, M, N, 512, false, p.pmax, p.pidx);
@@ -998,7 +999,7 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
     const int kk = 2 * nh;
     wdst.resize(wsrc.size());
     for (size_t i = 0; i < wsrc.size(); i++) wdst[i] = f32_to_bf16_host(wsrc[i]);
-    h->h_cls_wnorm.assign(nclass, 0.f);
+    h->h_cls_wnorm.assign(((size_t)nclass + 7) / 8 * 8, 0.f);   // padded: the select kernel loads eight at a time
     for (int c = 0; c < nclass; c++) {
       double ss = 0;
       for (int k = 0; k < kk; k++) ss += (double)wsrc[(size_t)c * kk + k] * wsrc[(size_t)c * kk + k];

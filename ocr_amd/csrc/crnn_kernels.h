@@ -253,10 +253,10 @@ void launch_resize_v(const uint8_t* src, const ResizeJob* jobs, const int32_t* c
 // ConvGemm is reused with A / Wt (and C when out_bf16) pointing at bf16 data; K % 64 == 0.
 void launch_conv_gemm_bf16(const ConvGemm& p, bool out_bf16, hipStream_t s);
 // Certified bf16 pre-filter of the classifier arg-max (see crnn_kernels.hip): A fp32 [M][K] -> bf16 copy + row
-// norms; then, from the bf16 GEMM's logits L [M][N], idx[row] = exact fp32 arg-max over the certified candidates.
+// norms; then, from the bf16 GEMM's logits L [M][N] (bf16), idx[row] = exact fp32 arg-max over the certified candidates.
 void launch_rows_to_bf16(const float* A, uint16_t* out, float* norm, int M, int K, hipStream_t s);
-void launch_cls_select(const float* L, const float* A, const float* W, const float* bias, const float* anorm,
-                       const float* wnorm, int32_t* idx, int M, int N, int K, hipStream_t s);
+void launch_cls_select(const uint16_t* L, const float* A, const float* W, const float* bias, const float* anorm,
+                       const float* wnorm, int32_t* idx, int M, int N, int K, int ldl, hipStream_t s);   // ldl % 8 == 0, N <= 8192
 void launch_conv0_pool_bf16(const float* in, const float* w9x64, const float* bias, void* out,
                             const int32_t* w1valid, int B, int W, int act, hipStream_t s);
 void launch_pool_2x2s2_bf16(const void* in, void* out, int B, int H, int W, int C, hipStream_t s);

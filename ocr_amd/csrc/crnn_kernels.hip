@@ -2187,7 +2187,8 @@ void launch_argmax_partials(const float* pmax, const int32_t* pidx, int32_t* idx
 // Certified bf16 pre-filter for the classifier's arg-max (fp32 path, logits not requested).
 // The arg-max over 5530 classes needs every logit only to know which one is largest, and the bf16 MFMA is 16x
 // faster than the f32 one.  So: (1) the activations are rounded to bf16 (RNE) and their row norms ||a|| taken;
-// (2) the bf16 GEMM writes approximate logits l~ (fp32 accumulate, exact bf16 x bf16 products); (3) per row, with
+// (2) the bf16 GEMM writes approximate logits l~ (fp32 accumulate, exact bf16 x bf16 products; stored as bf16, whose
+// rounding is added to the bound); (3) per row, with
 // the rigorous bound |l~_c - l_c| <= e_c = (2u + u^2) ||a|| ||w_c||  (u = 2^-8, Cauchy-Schwarz over the per-term
 // rounding errors, plus slack for the fp32 accumulation), every class whose upper bound l~_c + e_c reaches the best
 // lower bound max_c (l~_c - e_c) is a candidate -- the true arg-max is certainly among them -- and (4) the
@@ -2213,30 +2214,55 @@ __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restri
   if (lane == 0) norm[row] = sqrtf(ss) * 1.000001f;
 }
 
-__global__ __launch_bounds__(256) void cls_select_kernel(const float* __restrict__ L, const float* __restrict__ A,
+constexpr int CLS_MAXCH = 16;   // chunks of 512 classes a row may have (N <= 8192)
+__global__ __launch_bounds__(256) void cls_select_kernel(const uint16_t* __restrict__ L, const float* __restrict__ A,
                                                          const float* __restrict__ W, const float* __restrict__ bias,
                                                          const float* __restrict__ anorm,
                                                          const float* __restrict__ wnorm, int32_t* __restrict__ idx,
-                                                         int M, int N, int K) {
-  // one wave per row; the row is walked in chunks of 8 x 64 classes whose loads are issued together (a plain
-  // strided loop would pay the L2 latency once per 64 classes)
-  constexpr int U = 8;
+                                                         int M, int N, int K, int ldl) {
+  // One wave per row.  The approximate logits are stored as bf16 in rows of ldl (a multiple of 8) elements, so a
+  // lane reads eight classes per 16-byte load and the whole row (<= 16 loads per lane, issued together) stays in
+  // registers for both steps: best lower bound, then candidates.  The bf16 storage rounding, at most 2^-8 |l|
+  // (0.004 |l| used), is added to the bound.
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
-  const float* l = L + (long)row * N;
+  const uint4* l = (const uint4*)(L + (long)row * ldl);
   // (2u + u^2) with u = 2^-8 is 0.0078278; 0.00785 leaves room for the fp32 accumulation of 512 terms
   const float an = anorm[row] * 0.00785f;
-  float lb = -INFINITY;
-  for (int c0 = 0; c0 < N; c0 += 64 * U) {
-    float lv[U], wn[U];
+  uint4 v[CLS_MAXCH];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int c = c0 + u * 64 + lane;
-      lv[u] = c < N ? l[c] : -INFINITY;
-      wn[u] = c < N ? wnorm[c] : 0.f;
+  for (int ch = 0; ch < CLS_MAXCH; ch++) {
+    const int c = ch * 512 + lane * 8;
+    v[ch] = c < N ? l[ch * 64 + lane] : uint4{0, 0, 0, 0};
+  }
+  auto val = [&](const uint4& q, int e) {   // element e of the eight bf16 in q
+    const unsigned w = e < 2 ? q.x : (e < 4 ? q.y : (e < 6 ? q.z : q.w));
+    return __builtin_bit_cast(float, (e & 1) ? (w & 0xFFFF0000u) : (w << 16));
+  };
+  // e_c for this lane's eight classes of chunk ch (wnorm is padded with zeros to a multiple of 8 by the host)
+  auto bounds = [&](int ch, float (&lo)[8], float (&hi)[8]) {
+    const int c = ch * 512 + lane * 8;
+    const bool in = c < N;
+    const f32x4 w0 = in ? *(const f32x4*)(wnorm + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 w1 = in ? *(const f32x4*)(wnorm + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float x = val(v[ch], e);
+      const float ec = an * (e < 4 ? w0[e & 3] : w1[e & 3]) + 0.004f * __builtin_fabsf(x);
+      const bool ok = c + e < N;
+      lo[e] = ok ? x - ec : -INFINITY;
+      hi[e] = ok ? x + ec : -INFINITY;
     }
+  };
+  float lb = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < U; u++) lb = fmaxf(lb, lv[u] - an * wn[u]);
+  for (int ch = 0; ch < CLS_MAXCH; ch++) {
+    if (ch * 512 < N) {
+      float lo[8], hi[8];
+      bounds(ch, lo, hi);
+#pragma unroll
+      for (int e = 0; e < 8; e++) lb = fmaxf(lb, lo[e]);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) lb = fmaxf(lb, __shfl_xor(lb, off));
@@ -2244,21 +2270,25 @@ __global__ __launch_bounds__(256) void cls_select_kernel(const float* __restrict
   __shared__ int cand_s[4][64];
   int* cand = cand_s[threadIdx.x >> 6];
   int count = 0;
-  for (int c0 = 0; c0 < N; c0 += 64 * U) {
-    float lv[U], wn[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int c = c0 + u * 64 + lane;
-      lv[u] = c < N ? l[c] : -INFINITY;
-      wn[u] = c < N ? wnorm[c] : 0.f;
-    }
+  for (int ch = 0; ch < CLS_MAXCH; ch++) {
+    if (ch * 512 < N) {
+      float lo[8], hi[8];
+      bounds(ch, lo, hi);
+      unsigned mine = 0;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      unsigned long long m = __ballot(lv[u] + an * wn[u] >= lb);   // -inf (past N) never qualifies
-      while (m) {
-        if (count < 64 && lane == 0) cand[count] = c0 + u * 64 + __builtin_ctzll(m);
-        count++;
-        m &= m - 1;
+      for (int e = 0; e < 8; e++) mine |= hi[e] >= lb ? 1u << e : 0u;
+      unsigned long long lanes = __ballot(mine != 0);   // most chunks hold no candidate at all
+      while (lanes) {
+        const int src = __builtin_ctzll(lanes);
+        lanes &= lanes - 1;
+        unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)mine, src);
+        while (bits) {
+          const int e = __builtin_ctz(bits);
+          bits &= bits - 1;
+          if (count < 64 && lane == 0) cand[count] = ch * 512 + src * 8 + e;
+          count++;
+        }
       }
     }
   }
@@ -2277,8 +2307,8 @@ __global__ __launch_bounds__(256) void cls_select_kernel(const float* __restrict
   auto consider = [&](float part, int cc) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-    const float v = part + bias[cc];
-    if (v > best || (v == best && cc < bi)) { best = v; bi = cc; }
+    const float s = part + bias[cc];
+    if (s > best || (s == best && cc < bi)) { best = s; bi = cc; }
   };
   if (K == 512 && count <= 64) {
     const f32x4 a0 = *(const f32x4*)(a + lane * 4), a1 = *(const f32x4*)(a + 256 + lane * 4);
@@ -2303,10 +2333,12 @@ __global__ __launch_bounds__(256) void cls_select_kernel(const float* __restrict
         consider(part, cc[u]);
       }
     }
-  } else {   // general K, or more candidates than the list holds: walk the row again, one candidate at a time
+  } else {   // general K, or more candidates than the list holds: every class of the row that qualifies, one at a time
+    const uint16_t* ls = L + (long)row * ldl;
     for (int c0 = 0; c0 < N; c0 += 64) {
       const int c = c0 + lane;
-      unsigned long long m = __ballot(c < N && l[c] + an * wnorm[c] >= lb);
+      const float x = c < N ? __builtin_bit_cast(float, (unsigned)ls[c] << 16) : -INFINITY;
+      unsigned long long m = __ballot(c < N && x + (an * wnorm[c < N ? c : 0] + 0.004f * __builtin_fabsf(x)) >= lb);
       while (m) {
         const int cc = c0 + __builtin_ctzll(m);
         m &= m - 1;
@@ -2327,9 +2359,10 @@ __global__ __launch_bounds__(256) void cls_select_kernel(const float* __restrict
 void launch_rows_to_bf16(const float* A, uint16_t* out, float* norm, int M, int K, hipStream_t s) {
   hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((M + 3) / 4), dim3(256), 0, s, A, out, norm, M, K);
 }
-void launch_cls_select(const float* L, const float* A, const float* W, const float* bias, const float* anorm,
-                       const float* wnorm, int32_t* idx, int M, int N, int K, hipStream_t s) {
-  hipLaunchKernelGGL(cls_select_kernel, dim3((M + 3) / 4), dim3(256), 0, s, L, A, W, bias, anorm, wnorm, idx, M, N, K);
+void launch_cls_select(const uint16_t* L, const float* A, const float* W, const float* bias, const float* anorm,
+                       const float* wnorm, int32_t* idx, int M, int N, int K, int ldl, hipStream_t s) {
+  hipLaunchKernelGGL(cls_select_kernel, dim3((M + 3) / 4), dim3(256), 0, s, L, A, W, bias, anorm, wnorm, idx, M, N, K,
+                     ldl);
 }
 
 void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld, hipStream_t s) {

@@ -34,7 +34,8 @@ for tag in ("noise", "text"):
     an = np.sqrt((a.astype(np.float64) ** 2).sum(1))
     exact = a.astype(np.float64) @ W.astype(np.float64).T + b
     approx = to_bf16(a).astype(np.float64) @ W16.astype(np.float64).T + b
-    eps = 0.00785 * an[:, None] * wn[None, :]
+    approx = to_bf16(approx.astype(np.float32)).astype(np.float64)      # the kernel stores them as bf16
+    eps = 0.00785 * an[:, None] * wn[None, :] + 0.004 * np.abs(approx)
     assert (np.abs(approx - exact) <= eps).all(), "bound violated"
     lb = (approx - eps).max(1)
     cand = (approx + eps >= lb[:, None]).sum(1)
