@@ -331,7 +331,7 @@ def main():
     }
     if args.precision == "fp32" and os.environ.get("CRNN_CLS_FILTER", "1") != "0":
         out["config"]["classifier"] = ("arg-max decided in fp32: a bf16 GEMM with a rigorous error bound only prunes the "
-                                       "5530 classes to the candidates (3-4 per row here), which are scored exactly in fp32 "
+                                       "5530 classes to the candidates (about 4 per row here), which are scored exactly in fp32 "
                                        "(DESIGN.md section 4; CRNN_CLS_FILTER=0 = plain fp32 GEMM)")
         if plain:
             out["classifier_plain_fp32_gemm"] = plain
