@@ -748,27 +748,27 @@ void launch_wino_out(const float* Mo, const float* bias, float* y, const int32_t
 }
 
 // ---------------------------------------------------------------------------
-// Winograd F(4x4,3x3), interpolation points 0, +-1, +-2, inf (fp32):
-//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Winograd F(4x4,3x3) (fp32), interpolation points 0, 1, -1, 2, -1/2, inf.  The textbook set 0, +-1, +-2 was
+// measured to give three times the rounding error on conv1's input (tests/exp_winograd_f4_error.py);
+// all coefficients below are exact in binary floating point.
+//   B^T = [1 3/2 -2 -3/2 1 0; 0 -1 -5/2 -1/2 1 0; 0 1 1/2 -5/2 1 0; 0 -1/2 -1 1/2 1 0; 0 2 -1 -2 1 0; 0 1 3/2 -2 -3/2 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -1/2 0; 0 1 1 4 1/4 0; 0 1 -1 8 -1/8 1]
 // (G, applied to the weights on the host in double, is in crnn_api.hip.)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void wino4_bt(const f32x4 (&d)[6], f32x4 (&u)[6]) {
-  const f32x4 s12 = d[1] + d[2], d12 = d[1] - d[2], s34 = d[4] + d[3], d43 = d[4] - d[3];
-  const f32x4 d42 = d[4] - d[2], d31 = d[3] - d[1];
-  u[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-  u[1] = s34 - 4.f * s12;
-  u[2] = d43 + 4.f * d12;
-  u[3] = d42 + 2.f * d31;
-  u[4] = d42 - 2.f * d31;
-  u[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+  u[0] = d[0] + 1.5f * (d[1] - d[3]) - 2.f * d[2] + d[4];
+  u[1] = d[4] - d[1] - 2.5f * d[2] - 0.5f * d[3];
+  u[2] = d[4] + d[1] + 0.5f * d[2] - 2.5f * d[3];
+  u[3] = d[4] - d[2] + 0.5f * (d[3] - d[1]);
+  u[4] = d[4] - d[2] + 2.f * (d[1] - d[3]);
+  u[5] = d[1] + 1.5f * (d[2] - d[4]) - 2.f * d[3] + d[5];
 }
 __device__ __forceinline__ void wino4_at(const f32x4 (&m)[6], f32x4 (&r)[4]) {
-  const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-  r[0] = m[0] + s12 + s34;
-  r[1] = d12 + 2.f * d34;
-  r[2] = s12 + 4.f * s34;
-  r[3] = d12 + 8.f * d34 + m[5];
+  const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2];
+  r[0] = m[0] + s12 + m[3] + m[4];
+  r[1] = d12 + 2.f * m[3] - 0.5f * m[4];
+  r[2] = s12 + 4.f * m[3] + 0.25f * m[4];
+  r[3] = d12 + 8.f * m[3] - 0.125f * m[4] + m[5];
 }
 
 // One thread per (tile, 4 channels): 36 float4 loads (the 6x6 patch; neighbours' overlaps are L1/L2 hits),

@@ -27,7 +27,14 @@ AT4 = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0]
 BT2 = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
 G2 = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
 AT2 = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
-SETS = {2: (BT2, G2, AT2), 4: (BT4, G4, AT4)}
+# F(4,3) with the points 0, 1, -1, 2, -1/2, inf (what the kernels use: about 3x less rounding error than +-1, +-2)
+BT4B = torch.tensor([[1, 1.5, -2, -1.5, 1, 0], [0, -1, -2.5, -.5, 1, 0], [0, 1, .5, -2.5, 1, 0],
+                     [0, -.5, -1, .5, 1, 0], [0, 2, -1, -2, 1, 0], [0, 1, 1.5, -2, -1.5, 1]], dtype=torch.float64)
+G4B = torch.tensor([[1, 0, 0], [-1 / 3, -1 / 3, -1 / 3], [1 / 3, -1 / 3, 1 / 3], [1 / 15, 2 / 15, 4 / 15],
+                    [-16 / 15, 8 / 15, -4 / 15], [0, 0, 1]], dtype=torch.float64)
+AT4B = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -.5, 0], [0, 1, 1, 4, .25, 0], [0, 1, -1, 8, -.125, 1]],
+                    dtype=torch.float64)
+SETS = {2: (BT2, G2, AT2), 4: (BT4, G4, AT4), 5: (BT4B, G4B, AT4B)}   # 5 = the 4-output form with the better points
 
 
 class WinoConv(nn.Module):
@@ -46,7 +53,7 @@ class WinoConv(nn.Module):
 
     def forward(self, x):
         n, c, h, w = x.shape
-        mh, mw = self.mh, self.mw
+        mh, mw = min(self.mh, 4), min(self.mw, 4)
         th, tw = -(-h // mh), -(-w // mw)
         xp = F.pad(x, (1, tw * mw - w + 1, 1, th * mh - h + 1))
         # patches [n, c, th, tw, mh+2, mw+2]
@@ -120,6 +127,8 @@ def main():
                 ("F4x4 c1-5", [1, 2, 3, 4, 5], 4, 4), ("F4x4 c2-5", [2, 3, 4, 5], 4, 4),
                 ("F4x4 c4-5", [4, 5], 4, 4), ("F4x4 c1", [1], 4, 4), ("F(4,2) c6", [6], 4, 4),
                 ("F4x4 c1-5 + F(4,2) c6", [1, 2, 3, 4, 5, 6], 4, 4),
+                ("F4x4' c1-5 (pts 2,-1/2)", [1, 2, 3, 4, 5], 5, 5), ("F4x4' c2-5 (pts 2,-1/2)", [2, 3, 4, 5], 5, 5),
+                ("F4x4' c1 (pts 2,-1/2)", [1], 5, 5),
                 ("F4x4 c1 f64 transforms", [1], 4, 4, (1,)), ("F4x4 c1-5 f64 transforms", [1, 2, 3, 4, 5], 4, 4, (1, 2, 3, 4, 5))]
     torch.set_num_threads(8)
     # the hardest line of the GPU suite: uniform noise (stage test), here with the 65-class head

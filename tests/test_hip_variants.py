@@ -42,9 +42,9 @@ VARIANTS = [
     ({**F2, "CRNN_WINO_DMA": "3"}, 1),                        # 64x64 tiles
     (F2, 4),                                                  # F(2x2) per-launch tile choice, lanes sharing the device
     ({**F2, "CRNN_WINOGRAD": "0x38"}, 2),                     # F(2x2) on conv3-5 only
-    ({}, 1),                                                  # default: F(4x4) on conv2-5, fused F(2x2) on conv1, F(4,2) on conv6
+    ({}, 1),                                                  # default: F(4x4) on conv1-5 (pool1-3 in output transforms), F(4,2) on conv6
     ({}, 4),
-    ({"CRNN_WINOGRAD_F4": "0x3E"}, 2),                        # F(4x4) on conv1 too (pool1 in its output transform)
+    ({"CRNN_WINOGRAD_F4": "0x3C"}, 2),                        # conv1 on the fused F(2x2) kernel
     ({"CRNN_WINO4_SHAPE": "2"}, 1),                           # F(4x4) GEMM units of 128x64
     ({"CRNN_WINOGRAD_F4": "0x30", "CRNN_WINOGRAD": "0x08"}, 1),   # F(4x4) conv4-5, F(2x2) conv3, direct conv1-2
     ({"CRNN_WINO4_LW": "0"}, 1),                              # F(4x4) GEMM without the loader wave (every wave loads)

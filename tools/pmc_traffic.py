@@ -21,10 +21,10 @@ for _k in ORDER_FUSED:
     ORDER_HYBRID.append(_k)
     if _k in ("conv1_pool1", "conv2", "conv3", "conv4", "conv5"):
         ORDER_HYBRID.append(_k + "_tail")
-# f4 (fp32 default): conv1 fused F(2x2) + pool1 (two launches), conv2-5 as F(4x4): transform, GEMM, transform
-# (pool2 / pool3 inside the output transforms of conv3 / conv5)
-ORDER_F4 = ["normalize", "conv0_pool0", "conv1_win", "conv1_pool1", "conv1_pool1_tail"]
-for _l in (2, 3, 4, 5):
+# f4 (fp32 default): conv1-5 as F(4x4): transform, GEMM, transform (pool1 / pool2 / pool3 inside the output
+# transforms of conv1 / conv3 / conv5)
+ORDER_F4 = ["normalize", "conv0_pool0"]
+for _l in (1, 2, 3, 4, 5):
     ORDER_F4 += ["conv%d_win4" % _l, "conv%d_f4" % _l,
                  "conv%d_wout4" % _l + {3: "_pool2", 5: "_pool3"}.get(_l, "")]
 ORDER_F4 += ["conv6_win4", "conv6_f4", "conv6_wout4",   # conv6 as 1-D F(4,2)
