@@ -250,7 +250,7 @@ def main():
     wino_names = [n for n in gemm_names if (n.split("_")[0] + "_win") in order]
     wino4_names = [n for n in gemm_names if n.endswith("_f4")]
     lin_on = args.precision == "fp32" and os.environ.get("CRNN_LIN_GEMM", "1") != "0"
-    lin_names = [n for n in gemm_names if lin_on and n in ("lstm0_ih", "lstm1_ih", "classifier")]
+    lin_names = [n for n in gemm_names if lin_on and n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
     direct_names = [n for n in gemm_names if n not in wino_names + wino4_names + lin_names]
     direct_kernel = "conv_gemm_kernel" if args.precision == "fp32" else "conv_gemm_bf16_kernel"
 
@@ -275,7 +275,8 @@ def main():
     if lin_names:
         fams.append(family("lin_gemm_kernel", lin_names, "plain GEMMs as persistent launches of 128x128 units: " +
                            ", ".join(lin_names)))
-    fams.append(family(direct_kernel, direct_names, "implicit GEMM: " + ", ".join(direct_names)))
+    if direct_names:
+        fams.append(family(direct_kernel, direct_names, "implicit GEMM: " + ", ".join(direct_names)))
     fams.sort(key=lambda f: -f["ms_per_step"])
     dom = fams[0]
     gemm_names = dom["launches"]

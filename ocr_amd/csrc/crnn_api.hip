@@ -421,7 +421,10 @@ void kmark(crnn_handle* h, const char* name, double flop, double bytes) {
 // fp32 GEMMs with at least 256 units' worth of columns x rows... go through the persistent direct-to-LDS kernel
 // (CRNN_LIN_GEMM=0: all through conv_gemm_kernel).  The arg-max partial layout depends on the kernel, so the
 // choice for the classifier must be the same in gemm() and in the reduction that follows: lin_partials().
-static bool use_lin_gemm(const crnn_handle* h, const ConvGemm& p) { return h->lin_gemm && p.N >= 512 && lin_gemm_ok(p); }
+static bool use_lin_gemm(const crnn_handle* h, const ConvGemm& p) {
+  // plain GEMMs from 256 columns (emb0: 284 units), the arg-max form from 512 (what the tests cover)
+  return h->lin_gemm && p.N >= (p.pmax ? 512 : 256) && lin_gemm_ok(p);
+}
 
 // out_bf16 only matters on the bf16 path (which GEMM outputs feed another GEMM)
 void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, const uint16_t* Wt16,
@@ -648,7 +651,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   int ntn = (h->cfg.nclass + 127) / 128;
   {
     ConvGemm q{};
-    q.M = M; q.N = h->cfg.nclass; q.K = 512; q.ks = 1;
+    q.M = M; q.N = h->cfg.nclass; q.K = 512; q.ks = 1; q.pmax = p.pmax;   // the same question gemm() asked
     if (!b16 && use_lin_gemm(h, q)) ntn *= 4;
   }
   if (!filtered) {
