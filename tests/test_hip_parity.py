@@ -285,3 +285,22 @@ def test_random_crops_against_oracle(hip_en, oracle_en):
         assert got[i] == orc.decode(idx, keys.alphabetEnglish), i
         assert tt[i] == len(idx) and np.array_equal(raw[i, :tt[i]], idx), i
         assert np.abs(logits[i, :tt[i]] - lg).max() < LOGIT_TOL, i
+
+
+@pytest.mark.gpu
+def test_width_edges_strings_against_oracle(hip_zh, hip_en, oracle_zh, oracle_en):
+    """Widths around every tiling edge of the conv stack (4x4 / 2x2 Winograd tiles, tile-row segments of the pooled
+    output transform, the 4-wide tiles of conv6's F(4,2), 128-row GEMM units) for both heads, one line per call and
+    as one ragged batch: decoded strings identical to the oracle's (the 5530-class head goes through the classifier's
+    bf16 pre-filter)."""
+    from oracle import oracle as orc
+    from ocr_amd.crnn import keys
+    widths = [8, 9, 11, 12, 13, 15, 16, 17, 19, 20, 21, 31, 32, 33, 35, 63, 64, 65, 127, 128, 129, 255, 256, 257,
+              259, 261, 263, 280, 511, 513, 1031]
+    rs = np.random.RandomState(5)
+    lines = [np.where(rs.rand(32, w) < 0.8, 200 + rs.randint(0, 50, (32, w)), rs.randint(0, 90, (32, w))).astype(np.uint8)
+             for w in widths]
+    for model, ora, alpha in ((hip_en, oracle_en, keys.alphabetEnglish), (hip_zh, oracle_zh, keys.alphabetChinese)):
+        want = [orc.predict_gray(ora, ln, alpha) for ln in lines]
+        assert [model.predict_lines([ln])[0] for ln in lines] == want
+        assert model.predict_lines(lines, max_batch=16, width_spread=1.5) == want
