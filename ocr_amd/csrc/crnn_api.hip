@@ -466,7 +466,9 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     launch_wino4_gemm(w, s);
     kmark(h, wn4[1][layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * 36 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
     static const bool fuse21 = !(getenv("CRNN_WINO4_POOL21") && atoi(getenv("CRNN_WINO4_POOL21")) == 0);
-    if (!fuse21) pool21_out = nullptr;
+    // the pooled form gives one thread a segment of a tile row: below ~128 lines there are too few of them and the
+    // separate kernels are quicker (n = 1: 0.048 vs 0.02 ms per layer)
+    if (!fuse21 || n < 128) pool21_out = nullptr;
     float* dst = pool_out ? pool_out : (pool21_out ? pool21_out : (float*)C);
     launch_wino4_out(wino_m, h->d_conv_b[layer], dst, wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1,
                      pool_out ? 1 : (pool21_out ? 2 : 0), s);

@@ -2006,7 +2006,7 @@ __global__ __launch_bounds__(256) void lstm_rec_split_kernel(const float* __rest
     xl_T[i] = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
   }
   const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, 0x7FFFFFFF, 0x00020000);
-  gu32_t* my_cnt = (gu32_t*)(cnt + dir * (gridDim.x >> 2) + grp);
+  (void)cnt;
   float c[4], h[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) { c[r] = 0.f; h[r] = 0.f; }
@@ -2061,38 +2061,49 @@ __global__ __launch_bounds__(256) void lstm_rec_split_kernel(const float* __rest
     if (active)   // write-through store: the output row AND the hand-off to the other three workgroups
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv4), rec_rsrc,
                                              (unsigned)((rowi * 512 + dir * 256 + myu) * 4), 0, 16);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned want = 4u * (unsigned)(s + 1);
+    // The other parts' h of this step.  The launcher filled the whole output tensor with the bit pattern
+    // 0xFFFFFFFF (no h value has it) and every row is written exactly once, so the data is its own arrival flag:
+    // each thread polls its three 16-byte chunks with sc1 loads (L1 bypassed) until all four words of each have
+    // changed -- no drain of the stores, no counter round trip, and no assumption that the 16 bytes arrive
+    // together.  Lines that have ended keep their old value.  Spins are bounded; see the time-out word.
+    {
+      i32x4 v[3];
+      bool act[3], pend[3];
+      unsigned ro[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int Tl = xl_T[i], ln = xl_line[i];
+        act[i] = s < Tl;
+        const int tl = dir ? (Tl - 1 - s) : s;
+        ro[i] = (unsigned)((((size_t)(b0 + ln) * T + tl) * 512 + dir * 256 + xl_unit[i]) * 4);
+        pend[i] = act[i];
+      }
       unsigned spins = 0;
-      while (__hip_atomic_load(my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 22) || __hip_atomic_load((gu32_t*)tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-          __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_fail = 1;
-          break;
-        }
+      bool fail = false;
+      while (pend[0] || pend[1] || pend[2]) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+          if (pend[i]) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, ro[i], 0, 16);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+          if (pend[i]) pend[i] = v[i][0] == -1 || v[i][1] == -1 || v[i][2] == -1 || v[i][3] == -1;
+        if (++spins > (1u << 20)) { fail = true; break; }
+        if ((spins & 255u) == 0 &&
+            __hip_atomic_load((gu32_t*)tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = true; break; }
+      }
+      if (fail) {
+        __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_fail = 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        float* dst = hs + (cur ^ 1) * LB * HS + xl_line[i] * HS + xl_unit[i];
+        if (act[i]) *(f32x4*)dst = __builtin_bit_cast(f32x4, v[i]);
+        else *(f32x4*)dst = *(const f32x4*)(hs + cur * LB * HS + xl_line[i] * HS + xl_unit[i]);
       }
     }
     __syncthreads();
     if (s_fail) return;     // uniform: everybody leaves; the host repeats the batch with lstm_rec_kernel
-    // the other parts' h of this step (sc1 loads), or the old value for lines that have ended
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int Tl = xl_T[i], ln = xl_line[i];
-      const bool act = s < Tl;
-      const int tl = dir ? (Tl - 1 - s) : s;
-      float* dst = hs + (cur ^ 1) * LB * HS + ln * HS + xl_unit[i];
-      if (act) {
-        const size_t ro = ((size_t)(b0 + ln) * T + tl) * 512 + dir * 256 + xl_unit[i];
-        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (unsigned)(ro * 4), 0, 16);
-        *(f32x4*)dst = __builtin_bit_cast(f32x4, v);
-      } else {
-        *(f32x4*)dst = *(const f32x4*)(hs + cur * LB * HS + ln * HS + xl_unit[i]);
-      }
-    }
     __syncthreads();
     cur ^= 1;
   }
@@ -2102,7 +2113,9 @@ __global__ __launch_bounds__(256) void lstm_rec_split_kernel(const float* __rest
 void launch_lstm_rec_split(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,
                            int T, unsigned* cnt, unsigned* tmo, hipStream_t s) {
   const int groups = (B + LB - 1) / LB;
-  (void)hipMemsetAsync(cnt, 0, ((size_t)2 * groups * 4 + 15) / 16 * 16, s);
+  (void)cnt;
+  // the output rows double as arrival flags: fill them with a bit pattern no h value has
+  (void)hipMemsetAsync(rec, 0xFF, (size_t)B * T * 512 * sizeof(float), s);
   hipLaunchKernelGGL(lstm_rec_split_kernel, dim3(groups * 4, 2), dim3(256), 0, s, xp, whh_packed, rec, tlen, B, T,
                      cnt, tmo);
 }
