@@ -86,9 +86,10 @@ struct crnn_handle {
   std::vector<float> h_cls_wnorm;   // ||w_c|| of the classifier rows (rounded up)
   bool wino6 = true;      // conv6 as 1-D Winograd F(4,2) (fp32 path; CRNN_WINO6=0: implicit GEMM)
   bool lin_gemm = true;   // LSTM input projections and classifier on lin_gemm_kernel (CRNN_LIN_GEMM=0: conv_gemm_kernel)
-  // recurrence: batches of up to split_max lines (8 workgroups per 16 lines: 192 of the 256 CUs at 384) use the
-  // hidden-split latency kernel in the synchronous host paths (CRNN_LSTM_SPLIT=<max lines>, 0 = never)
-  int split_max = 384;
+  // recurrence: batches of up to split_max lines (4 workgroups per (direction, 16 lines): 256 workgroups, one per CU,
+  // at 512 lines -- all of them must be resident at once) use the hidden-split latency kernel in the synchronous host
+  // paths (CRNN_LSTM_SPLIT=<max lines>, 0 = never); measured faster than the one-workgroup kernel up to 1024 lines
+  int split_max = 512;
   // at most one hidden-split kernel runs at a time (each waits for the previous one's event): two of them, each
   // partly resident and spinning for workgroups that cannot be placed, would only end by their time-outs
   std::mutex split_mu;

@@ -245,7 +245,7 @@ def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh):
         os.environ["CRNN_LSTM_SPLIT"] = "0"
         ref = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1)
         ref.load_state_dict(synth_zh)
-        os.environ["CRNN_LSTM_SPLIT"] = "384"
+        os.environ["CRNN_LSTM_SPLIT"] = "512"
         spl = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1)
         spl.load_state_dict(synth_zh)
     finally:
@@ -265,6 +265,11 @@ def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh):
         for i in range(n):
             assert np.array_equal(a[2][i, :a[1][i]], b[2][i, :b[1][i]]), (n, i)
         assert ref.predict_lines(lines) == spl.predict_lines(lines)
+    # the largest batch that takes the split kernel: 512 narrow lines (256 workgroups, one per CU), ragged widths
+    lines = [rs.randint(0, 256, size=(32, int(w))).astype(np.uint8) for w in rs.randint(40, 90, size=512)]
+    a = ref._run(lines, 0, want_raw=True)     # 0 = PAD_PER_LINE: every line decoded as if alone
+    b = spl._run(lines, 0, want_raw=True)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
 
 
 @pytest.mark.gpu
