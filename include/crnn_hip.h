@@ -11,10 +11,21 @@
  * Conventions: plain pointers and sizes, no torch types.  Every function
  * returns 0 on success or a negative crnn_status; nothing throws across the
  * boundary.  The caller owns every buffer.  A handle is bound to one device
- * and one HIP stream and is internally mutex-guarded, so the two gunicorn
- * threads of a worker (gunicorn.conf.py:24) may share it.  Device state is
+ * and owns up to 8 lanes (a HIP stream plus a workspace each); it is internally
+ * mutex-guarded, so the two gunicorn threads of a worker (gunicorn.conf.py:24)
+ * may share it and run on different lanes at the same time.  Device state is
  * created lazily on the first call that needs it, so a handle may be created
  * before fork() (gunicorn preload_app, gunicorn.conf.py:57) and used after.
+ *
+ * Stream ordering of the device-pointer entry points (crnn_forward_device): the library queues its work on one of ITS OWN streams
+ * (created non-blocking: no implicit ordering with the NULL stream or with a
+ * framework's current stream).  Every input buffer must be completely written,
+ * and every output buffer free to be overwritten, before the call is made --
+ * either synchronise the producing stream first, or ask crnn_next_lane() which
+ * lane the next call will take and make crnn_stream(h, lane) wait on an event of
+ * the producer (hipStreamWaitEvent).  Results are complete when that lane's
+ * stream reaches the point after the call (sync != 0, crnn_synchronize, or an
+ * event recorded on crnn_stream(h, returned lane)).
  */
 #ifndef CRNN_HIP_H
 #define CRNN_HIP_H
@@ -142,6 +153,16 @@ CRNN_API int crnn_predict_page(crnn_handle* h, const uint8_t* page, int32_t heig
 CRNN_API int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_t w,
                         const int32_t* widths, int32_t* d_raw, int32_t* d_lab, int32_t* d_len,
                         int32_t sync);
+
+/* Lane (>= 0) the next crnn_forward_device call on this handle will be queued on, so that a single producer
+ * thread can order its own stream before that lane's stream (see "Stream ordering" above).  With several
+ * threads calling crnn_forward_device on one handle the answer can be stale by the time it is used. */
+CRNN_API int crnn_next_lane(crnn_handle* h);
+
+/* Number of times the hidden-split recurrence (small synchronous batches) gave up waiting for its partner
+ * workgroups on this handle and the batch was repeated with the one-workgroup kernel (a latency cliff a
+ * service wants to see; 0 in normal operation).  No reference counterpart. */
+CRNN_API int64_t crnn_split_timeouts(const crnn_handle* h);
 
 /* Debug taps for layer-by-layer parity: runs crnn_forward_device's network on normalised fp32
  * host input x [n,32,w] and copies stage `stage` (0 pool0, 1 pool1, 2 relu2, 3 pool2, 4 relu4,

@@ -18,7 +18,8 @@ FP32, BF16 = 0, 1
 
 SYMBOLS = ["crnn_create", "crnn_load_weights", "crnn_resized_width", "crnn_out_len", "crnn_preprocess",
            "crnn_predict_batch", "crnn_set_page", "crnn_predict_rects", "crnn_predict_page", "crnn_forward_device", "crnn_debug_stage", "crnn_synchronize", "crnn_stream", "crnn_lanes",
-           "crnn_last_timing", "crnn_set_profiling", "crnn_last_kernel_times", "crnn_last_error", "crnn_destroy"]
+           "crnn_last_timing", "crnn_set_profiling", "crnn_last_kernel_times", "crnn_last_error", "crnn_destroy",
+           "crnn_next_lane", "crnn_split_timeouts"]
 
 
 class Config(C.Structure):
@@ -129,6 +130,10 @@ def lib():
     L.crnn_last_error.argtypes = [vp]
     L.crnn_destroy.restype = None
     L.crnn_destroy.argtypes = [vp]
+    L.crnn_next_lane.restype = C.c_int
+    L.crnn_next_lane.argtypes = [vp]
+    L.crnn_split_timeouts.restype = C.c_int64
+    L.crnn_split_timeouts.argtypes = [vp]
     _lib = L
     return L
 

@@ -102,6 +102,24 @@ class CRNN(object):
     def eval(self):
         return self
 
+    def forward(self, input):
+        """network_torch.py:88-108: normalised input ``[b, 1, 32, w]`` (torch tensor or array, float32) ->
+        logits ``[T, b, nclass]``, time-major like the reference's ``forward`` (``conv.permute(2, 0, 1)``, :95).
+        A torch tensor in gives a torch tensor (CPU) out.  Every sample is taken at the full width w, as the
+        reference does (no per-line masks)."""
+        is_torch = hasattr(input, "detach")
+        x = input.detach().cpu().numpy() if is_torch else np.asarray(input)
+        if x.ndim != 4 or x.shape[1] != 1 or x.shape[2] != 32:
+            raise ValueError("expected input of shape [b, 1, 32, w], got %s" % (x.shape,))
+        out = self.debug_stage(np.ascontiguousarray(x[:, 0], dtype=np.float32), 10)      # [b, T, nclass]
+        out = np.ascontiguousarray(np.transpose(out, (1, 0, 2)))
+        if is_torch:
+            import torch
+            return torch.from_numpy(out)
+        return out
+
+    __call__ = forward
+
     # --------------------------------------------------------------- inference
     def _run(self, images, pad_mode, want_raw=False, want_logits=False):
         il = _capi.ImageList(images)
@@ -361,6 +379,14 @@ class CRNN(object):
 
     def synchronize(self):
         _capi.check(self._h, self._lib.crnn_synchronize(self._h))
+
+    def next_lane(self):
+        """Lane the next forward_device call will be queued on (to order a producer stream before it)."""
+        return _capi.check(self._h, self._lib.crnn_next_lane(self._h))
+
+    def split_timeouts(self):
+        """How often the hidden-split recurrence gave up and a batch was repeated (0 in normal operation)."""
+        return int(self._lib.crnn_split_timeouts(self._h))
 
     def texts_from_labels(self, lab, ln):
         """Host arrays lab [n,T] / ln [n] (as copied back from forward_device) -> list of str."""

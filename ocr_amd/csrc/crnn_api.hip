@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -54,7 +55,7 @@ struct Lane {
   DevBuf stage;      // PINNED HOST memory: packed sources on their way to the device
   std::mutex mu;     // held by whichever call is using this lane's stream and buffers
   bool split_used = false;   // the last run_network on this lane used the hidden-split recurrence
-  DevBuf sync;       // arrival counters + time-out word of the hidden-split recurrence
+  DevBuf sync;       // time-out word of the hidden-split recurrence
   DevBuf page;       // resident page of this lane (crnn_set_page uses lane 0, crnn_predict_page any free lane)
   int page_h = 0, page_w = 0, page_ch = 0;
   float* st[11] = {};          // where the stages of the last run live (crnn_debug_stage)
@@ -94,6 +95,7 @@ struct crnn_handle {
   // partly resident and spinning for workgroups that cannot be placed, would only end by their time-outs
   std::mutex split_mu;
   hipEvent_t split_ev = nullptr;
+  std::atomic<int64_t> split_timeouts{0};   // batches repeated because the hidden-split recurrence gave up (crnn_split_timeouts)
   bool wino_fused = true;   // GEMM + output transform in one kernel (CRNN_WINO_FUSED=0: separate kernels)
   // bf16 copies (precision == CRNN_BF16): conv1..6, W_ih, embeddings / linear, packed W_hh
   std::vector<uint16_t> hb_conv_w[7], hb_wih[2], hb_whhp[2], hb_emb_w[2], hb_lin_w;
@@ -129,7 +131,9 @@ struct crnn_handle {
   int nlanes = 1;
   int next_lane = 0;
   int next_host_lane = 0;
-  Lane* last = &lanes[0];    // lane of the most recent network run (timing / debug queries)
+  // lane of the most recent network run (timing / profiling queries; those are single-caller measurement aids:
+  // they lock that lane while they read its events, so a concurrent run cannot re-record them mid-query)
+  std::atomic<Lane*> last{&lanes[0]};
 };
 
 namespace {
@@ -598,7 +602,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   if (split) {
     int rc = ensure_buf(h, tl_cur->sync, 4096);
     if (rc) return rc;
-    d_sync = (unsigned*)tl_cur->sync.p;                       // [0..3] time-out word (+pad), [4..] counters
+    d_sync = (unsigned*)tl_cur->sync.p;                       // [0] the time-out word
     HIPCHK(h, hipMemsetAsync(d_sync, 0, 16, s));
   }
   tl_cur->split_used = split;
@@ -608,7 +612,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       std::lock_guard<std::mutex> lk(h->split_mu);
       if (!h->split_ev) (void)hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming);
       if (h->split_ev) (void)hipStreamWaitEvent(s, h->split_ev, 0);
-      launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync + 4, d_sync, s);
+      launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync, s);
       if (h->split_ev) (void)hipEventRecord(h->split_ev, s);
     }
     else launch_lstm_rec(p.xp, h->d_whhp[l], out, tlen, n, g.T, s);
@@ -665,7 +669,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   kmark(h, "ctc", 0, 4.0 * (2.0 * M + n));
   HIPCHK(h, hipEventRecord(tl_cur->ev[4], s));
   tl_cur->ev_valid = true;
-  h->last = tl_cur;
+  h->last.store(tl_cur, std::memory_order_release);
   HIPCHK(h, hipGetLastError());
   // remember where the stages live
   float* st[11] = {p.p0, p.p1, p.c2, p.p2, p.c4, p.p3, p.seq, p.mid, p.rec0, p.rec1, p.logits};
@@ -799,6 +803,17 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   if (!h) return CRNN_ERR_NOMEM;
   h->cfg = *cfg;
   h->nlanes = cfg->lanes <= 0 ? 1 : (cfg->lanes > MAX_LANES ? MAX_LANES : cfg->lanes);
+  // The lanes are HIP streams, which the runtime multiplexes over GPU_MAX_HW_QUEUES hardware queues (default 4, read
+  // when HIP initialises).  Four or more lanes on four queues are SLOWER than three (two lanes serialise on one queue:
+  // 7.25 against 5.9 ms per 256-line step), so without at least 8 queues the handle keeps three lanes.
+  // CRNN_EFFECTIVE_HW_QUEUES: what the runtime really uses when the variable was changed after HIP came up
+  // (ocr_amd/crnn/_capi.py sets it in that case).
+  {
+    const char* e = getenv("CRNN_EFFECTIVE_HW_QUEUES");
+    if (!e) e = getenv("GPU_MAX_HW_QUEUES");
+    const int q = e ? atoi(e) : 4;
+    if (q < 8 && h->nlanes > 3 && !getenv("CRNN_KEEP_LANES")) h->nlanes = 3;
+  }
   // Winograd layers (bit i = conv i, i in 1..5): default conv3..5 (measured best); CRNN_WINOGRAD=<mask> overrides (0 = off)
   h->wino_mask = cfg->precision == CRNN_FP32 ? 0x3Eu : 0u;
   if (const char* e = getenv("CRNN_WINO_FUSED")) h->wino_fused = atoi(e) != 0;
@@ -816,6 +831,8 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   if (cfg->precision != CRNN_FP32) h->wino6 = false;
   if (const char* e = getenv("CRNN_LSTM_SPLIT")) h->split_max = atoi(e);
   if (const char* e = getenv("CRNN_WINOGRAD")) h->wino_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
+  // a layer that always runs as F(4x4) needs no F(2x2) weight set (neither built at load nor uploaded)
+  if (h->wino4_min_n <= 1) h->wino_mask &= ~h->wino4_mask;
   for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);
   *out = h;
   return 0;
@@ -1106,8 +1123,10 @@ static int predict_core(crnn_handle* h, const uint8_t* const* imgs, const int32_
     unsigned tmo = 0;
     HIPCHK(h, hipMemcpyAsync(&tmo, tl_cur->sync.p, 4, hipMemcpyDeviceToHost, tl_cur->stream));
     HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
-    if (tmo && (rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len, out_logits != nullptr, false)))
-      return rc;
+    if (tmo) {
+      h->split_timeouts++;
+      if ((rc = run_network(h, g, p, uniform ? nullptr : wv.data(), d_lab, d_len, out_logits != nullptr, false))) return rc;
+    }
   }
   std::vector<int32_t> lab(nT), raw(nT), len(g.n);
   HIPCHK(h, hipMemcpyAsync(lab.data(), d_lab, nT * 4, hipMemcpyDeviceToHost, tl_cur->stream));
@@ -1334,16 +1353,25 @@ void* crnn_stream(crnn_handle* h, int32_t lane) {
   std::lock_guard<std::mutex> lk(h->mu);
   if (lane >= h->nlanes) return nullptr;
   tl_cur = &h->lanes[0];
-  if (ensure_device(h, false)) return nullptr;
+  if (ensure_device(h, h->loaded)) return nullptr;   // with the weights, if there are any: after this call nothing is left to allocate
   return (void*)h->lanes[lane].stream;
 }
 
 int crnn_lanes(const crnn_handle* h) { return h ? h->nlanes : CRNN_ERR_ARG; }
 
+int crnn_next_lane(crnn_handle* h) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  return h->next_lane;
+}
+
+int64_t crnn_split_timeouts(const crnn_handle* h) { return h ? h->split_timeouts.load() : 0; }
+
 int crnn_last_timing(crnn_handle* h, float ms[5]) {
   if (!h || !ms) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  Lane& L = *h->last;
+  Lane& L = *h->last.load(std::memory_order_acquire);
+  std::lock_guard<std::mutex> lane_lk(L.mu);
   if (!L.ev_valid) return fail(h, CRNN_ERR_STATE, "nothing has run yet");
   HIPCHK(h, hipEventSynchronize(L.ev[4]));
   for (int i = 0; i < 4; i++) HIPCHK(h, hipEventElapsedTime(&ms[i], L.ev[i], L.ev[i + 1]));
@@ -1363,7 +1391,8 @@ int crnn_last_kernel_times(crnn_handle* h, int32_t cap, const char** names, floa
                            double* bytes) {
   if (!h) return CRNN_ERR_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  Lane& L = *h->last;
+  Lane& L = *h->last.load(std::memory_order_acquire);
+  std::lock_guard<std::mutex> lane_lk(L.mu);
   if (!h->kprof || L.nk == 0) return 0;
   HIPCHK(h, hipEventSynchronize(L.kev[L.nk]));
   int n = L.nk < cap ? L.nk : cap;

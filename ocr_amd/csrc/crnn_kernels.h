@@ -205,11 +205,11 @@ void launch_pool_2x2s21p01(const float* in, float* out, int B, int H, int W, int
 void launch_lstm_rec(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen,
                      int B, int T, hipStream_t s);
 // Latency form for small batches: four workgroups per (direction, 16 lines), W_hh slices resident in
-// registers, h exchanged every step through rec with write-through stores and an arrival counter.
-// cnt: >= 2 * ceil(B/16) words (+ padding to 16 bytes), tmo: one word set to 1 if a hand-off timed out
-// (the caller then repeats the recurrence with launch_lstm_rec); both are zeroed / left by this call as said.
+// registers, h exchanged every step through rec itself (write-through stores; the rows double as arrival flags).
+// tmo: one device word the caller has zeroed, set to 1 if a hand-off timed out (the caller then repeats the
+// recurrence with launch_lstm_rec).
 void launch_lstm_rec_split(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,
-                           int T, unsigned* cnt, unsigned* tmo, hipStream_t s);
+                           int T, unsigned* tmo, hipStream_t s);
 // host-side repack of W_hh [2][1024][256] into the per-lane fragment order the kernel streams.
 void pack_whh(const float* whh_fwd, const float* whh_rev, float* packed /* 2*1024*256 */);
 

@@ -562,8 +562,9 @@ __global__ __launch_bounds__(128 * NWN, MT == 1 ? 3 : (NWN == 2 ? 2 : 1)) void w
   // waits below are written by hand.
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;   // bytes, wave uniform
   auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    unsigned m0_saved;   // M0 is restored: the compiler may keep a value of its own there (clobbering it is not allowed)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
   };
   // running descriptor bases (bytes): advance by one component when the K position wraps
   unsigned long long pa = (unsigned long long)p.V, pb = (unsigned long long)p.U;
@@ -1013,8 +1014,9 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino4_gemm_kernel
   const int nk = p.Cin / BK;
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;
   auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    unsigned m0_saved;   // M0 is restored: the compiler may keep a value of its own there (clobbering it is not allowed)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
   };
   // unit -> operand bases (wave uniform)
   auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) {
@@ -1182,8 +1184,9 @@ __global__ __launch_bounds__(576, 1) void wino4_gemm_lw_kernel(const Wino4Gemm p
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
     auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                   :: "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+      unsigned m0_saved;   // M0 is restored: the compiler may keep a value of its own there (clobbering it is not allowed)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     };
     int l_u = L, l_k0 = 0;
     unsigned long long pa, pb, pm;
@@ -1375,8 +1378,9 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
   const int nk = p.K / BK;
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;
   auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    unsigned m0_saved;   // M0 is restored: the compiler may keep a value of its own there (clobbering it is not allowed)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
   };
   const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.Wt;
   int l_u = first, l_k0 = 0;
@@ -1961,24 +1965,29 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(const float* __restrict__
 // units [64 part, 64 part + 64) of all four gates, wave w the 16 units [.. + 16 w, ..+16); the wave's
 // W_hh slice (4 gate tiles x 256 k = 64 KB) stays in registers for the whole launch, so a step is 256
 // MFMAs per wave (3.4 us) instead of 1024 plus 1 MiB of weight traffic.  The price is an exchange of h
-// every step, done through the output tensor itself (each step's rows are fresh addresses):
+// every step, done through the output tensor itself (each step's rows are fresh addresses), and the data
+// is its own arrival flag:
+//   * the launcher fills the output tensor with the bit pattern 0xFFFFFFFF (no h value has it);
 //   * every lane stores its 4 h values write-through (sc1) to rec[line, t, dir, unit..] (the kernel's output
-//     anyway), every wave drains (s_waitcnt vmcnt(0)), the workgroup barriers, one lane adds 1 to the
-//     group's arrival counter with an agent-scope atomic;
-//   * one lane polls the counter (relaxed, agent scope, bounded) until all four parts of this step have
-//     arrived; then the other parts' 3 x 64 units of every active line are loaded with sc1 loads (L1 is
-//     bypassed; nothing here depends on which XCD a workgroup landed on) into the LDS copy of h.
-// A line that is past its own length publishes nothing; everybody keeps its old h from LDS.
+//     anyway) and goes straight on to poll the three 16-byte chunks it needs from the other parts with sc1
+//     loads (L1 bypassed) until all four words of each have changed -- no drain of the stores, no barrier, no
+//     counter, and no assumption that the 16 bytes of a chunk arrive together; nothing here depends on which
+//     XCD a workgroup landed on.  The chunks go into the LDS copy of h.
+// A line that is past its own length publishes nothing; everybody keeps its old h from LDS.  When the loop is
+// over the rows t >= T_i of every line (never written: still the fill pattern, a NaN) are set to zero.
 // The same packed weights, the same MFMA sequence per accumulator and the same gate math as the kernel
-// above: results are bit-identical (tests/test_hip_scale.py).  Spins are bounded: a workgroup that waits
-// too long sets *tmo and every workgroup leaves; the host then repeats the batch with the kernel above.
+// above: results are bit-identical (tests/test_hip_scale.py).  Spins are bounded (SPLIT_MAX_SPINS polls, some
+// tens of milliseconds): a workgroup that waits too long sets *tmo and every workgroup leaves; the host then
+// repeats the batch with the kernel above and counts the event (crnn_split_timeouts).  A weight that makes an
+// h value the fill pattern itself (a NaN with all bits set) ends the same way.
 // ---------------------------------------------------------------------------
+constexpr unsigned SPLIT_MAX_SPINS = 1u << 16;
 typedef __attribute__((address_space(1))) unsigned gu32_t;
 
 __global__ __launch_bounds__(256) void lstm_rec_split_kernel(const float* __restrict__ xp,
                                                              const float* __restrict__ whhp, float* rec,
                                                              const int32_t* __restrict__ tlen, int B, int T,
-                                                             unsigned* cnt, unsigned* tmo) {
+                                                             unsigned* tmo) {
   __shared__ __attribute__((aligned(16))) float hs[2 * LB * HS];
   __shared__ int s_fail;
   const int dir = blockIdx.y, grp = blockIdx.x >> 2, part = blockIdx.x & 3, b0 = grp * LB;
@@ -2006,7 +2015,6 @@ __global__ __launch_bounds__(256) void lstm_rec_split_kernel(const float* __rest
     xl_T[i] = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
   }
   const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, 0x7FFFFFFF, 0x00020000);
-  (void)cnt;
   float c[4], h[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) { c[r] = 0.f; h[r] = 0.f; }
@@ -2087,7 +2095,7 @@ __global__ __launch_bounds__(256) void lstm_rec_split_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 3; i++)
           if (pend[i]) pend[i] = v[i][0] == -1 || v[i][1] == -1 || v[i][2] == -1 || v[i][3] == -1;
-        if (++spins > (1u << 20)) { fail = true; break; }
+        if (++spins > SPLIT_MAX_SPINS) { fail = true; break; }
         if ((spins & 255u) == 0 &&
             __hip_atomic_load((gu32_t*)tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = true; break; }
       }
@@ -2107,17 +2115,26 @@ __global__ __launch_bounds__(256) void lstm_rec_split_kernel(const float* __rest
     __syncthreads();
     cur ^= 1;
   }
+  // padding rows (t >= T_i) of this workgroup's lines, direction and 64 units: zero instead of the fill pattern
+  for (int ln = 0; ln < LB; ln++) {
+    const int bb = b0 + ln;
+    if (bb >= B) break;
+    const int Tl = tlen ? tlen[bb] : T;
+    for (int r = Tl * 16 + tid; r < T * 16; r += 256)
+      *(f32x4*)(rec + ((size_t)bb * T + (r >> 4)) * 512 + dir * 256 + part * 64 + (r & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 
-// cnt: 2 * groups counters (zeroed here), tmo: one word (zeroed here); both device memory
+// tmo: one device word, zeroed by the caller, set to 1 by the kernel when a hand-off timed out
 void launch_lstm_rec_split(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,
-                           int T, unsigned* cnt, unsigned* tmo, hipStream_t s) {
+                           int T, unsigned* tmo, hipStream_t s) {
   const int groups = (B + LB - 1) / LB;
-  (void)cnt;
-  // the output rows double as arrival flags: fill them with a bit pattern no h value has
+  // the output rows double as arrival flags: fill them with a bit pattern no h value has (every row a step can
+  // poll must carry it, and with ragged lengths those rows are scattered, so the whole tensor is filled: 37 MB at
+  // 256 lines, ~10 us)
   (void)hipMemsetAsync(rec, 0xFF, (size_t)B * T * 512 * sizeof(float), s);
   hipLaunchKernelGGL(lstm_rec_split_kernel, dim3(groups * 4, 2), dim3(256), 0, s, xp, whh_packed, rec, tlen, B, T,
-                     cnt, tmo);
+                     tmo);
 }
 
 void launch_lstm_rec(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,

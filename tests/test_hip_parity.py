@@ -221,38 +221,79 @@ def test_load_weights_pth_with_module_prefix(tmp_path, golden, synth_en):
 
 
 @pytest.mark.gpu
-def test_page_rectangles_equal_cropped_lines(golden, hip_zh):
-    """crops given as rectangles of one resident page decode exactly as the same crops
-    cut on the host (CRNN.ocr on page[y1:y2, x1:x2], ocr_context.py:119 fed by vat_detect.py:318)."""
+def test_page_rectangles_against_oracle(golden, hip_zh, oracle_zh):
+    """crops given as rectangles of one resident page decode exactly as the reference decodes the same
+    crops cut on the host (CRNN.ocr on page[y1:y2, x1:x2], ocr_context.py:119 fed by vat_detect.py:291,318).  The
+    expected strings come from the CPU oracle on the host-cut crops and, for the pasted invoice crops, from the
+    goldens captured from the reference itself -- not from the HIP path."""
+    from oracle import oracle as orc
     from ocr_amd.ocr_context import CrnnOcrContext
     G, M = golden
     rs = np.random.RandomState(7)
     page = rs.randint(0, 256, size=(600, 900, 3)).astype(np.uint8)
     # paste the invoice crops so that real text-like content is on the page
-    rects, y = [], 5
-    for k in sorted(k for k in G.files if k.startswith("inv/") and k.endswith("/bgr"))[:8]:
-        c = G[k]
+    rects, gold, y = [], [], 5
+    for it in sorted(M["invoice"], key=lambda it: it["name"])[:8]:
+        c = G["inv/%s/bgr" % it["name"]]
         h, w = c.shape[:2]
         if y + h > page.shape[0] or w + 7 > page.shape[1]:
             continue
         page[y:y + h, 7:7 + w] = c
         rects.append((7, y, 7 + w, y + h))
+        gold.append(it["zh"])
         y += h + 3
+    assert len(gold) >= 4
     rects += [(100, 300, 420, 333), (0, 0, 900, 40), (850, 550, 2000, 2000), (10, 500, 14, 540), (300, 100, 308, 140)]
-    want = [hip_zh.ocr(page[y1:y2, x1:x2]) for x1, y1, x2, y2 in rects]
+
+    def oracle_text(crop):
+        g = orc.bgr_to_gray(crop) if crop.ndim == 3 else crop
+        if orc.resize_normalize(g).shape[-1] < 8:
+            return ""                                      # network_torch.py:141-142
+        return orc.predict_gray(oracle_zh, g, keys.alphabetChinese)
+    want = [oracle_text(page[y1:y2, x1:x2]) for x1, y1, x2, y2 in rects]
+    assert want[:len(gold)] == gold                        # the oracle agrees with the reference on the pasted crops
     assert hip_zh.ocr_page(page, rects) == want
+    assert [hip_zh.ocr(page[y1:y2, x1:x2]) for x1, y1, x2, y2 in rects] == want
+    hip_zh.set_page(page)
+    assert hip_zh.predict_rects(rects) == want
     # a strided view of a larger array as the page, gray pages, and the adapter's conventions
     big = np.zeros((700, 1000, 3), np.uint8)
     big[50:650, 60:960] = page
     assert hip_zh.ocr_page(big[50:650, 60:960], rects) == want
     gray = page[:, :, 1].copy()
     hip_zh.set_page(gray)
-    assert hip_zh.predict_rects(rects[:4]) == hip_zh.predict_lines([gray[y1:y2, x1:x2] for x1, y1, x2, y2 in rects[:4]])
+    assert hip_zh.predict_rects(rects[:4]) == [oracle_text(gray[y1:y2, x1:x2]) for x1, y1, x2, y2 in rects[:4]]
     ctx = CrnnOcrContext(hip_zh)
     got = ctx.page_ocr(page, rects + [(5, 5, 5, 30), (-3, 0, 10, 10)])
     assert got[:len(rects)] == want and got[len(rects):] == ["", ""]
     with pytest.raises(ZeroDivisionError):
         hip_zh.predict_rects([(5, 5, 50, 5)])
+
+
+@pytest.mark.gpu
+def test_forward_is_the_reference_forward(golden, hip_en, hip_zh):
+    """CRNN.forward / __call__ (network_torch.py:88-108): normalised [b,1,32,w] in, logits [T,b,nclass] out,
+    against the logits the reference's own forward gave (goldens)."""
+    import torch
+    G, M = golden
+    for it in M["invoice"][:6]:
+        n = it["name"]
+        x = ((G["inv/%s/resized" % n] / 255.0 - 0.5) / 0.5).astype(np.float32)[None, None]
+        out = hip_en(x)
+        ref = G["inv/%s/en_logits" % n]
+        assert out.shape == (ref.shape[0], 1, 65)
+        assert np.abs(out[:, 0] - ref).max() < LOGIT_TOL, n
+    n = "invoice_number"
+    x = torch.from_numpy(((G["inv/%s/resized" % n] / 255.0 - 0.5) / 0.5).astype(np.float32)[None, None])
+    out = hip_zh.forward(x)
+    assert isinstance(out, torch.Tensor) and tuple(out.shape) == (G["inv/%s/zh_logits" % n].shape[0], 1, 5530)
+    assert np.abs(out[:, 0].numpy() - G["inv/%s/zh_logits" % n]).max() < LOGIT_TOL
+    # a batch of two equal-width inputs: column b of the output is sample b
+    two = np.concatenate([x.numpy(), x.numpy()[:, :, :, ::-1]], 0)
+    o2 = hip_zh(two)
+    assert np.array_equal(o2[:, 0], out[:, 0].numpy()) and not np.array_equal(o2[:, 1], o2[:, 0])
+    with pytest.raises(ValueError):
+        hip_zh(np.zeros((1, 3, 32, 100), np.float32))
 
 
 @pytest.mark.gpu

@@ -299,6 +299,45 @@ def test_split_recurrences_of_concurrent_callers(golden, synth_en):
     for t in ts:
         t.join()
     assert not errs, errs
+    assert m.split_timeouts() == 0        # no batch had to be repeated with the one-workgroup kernel
+
+
+@pytest.mark.gpu
+def test_sharded_recognition_with_the_real_recogniser(synth_en, oracle_en):
+    """ocr_amd/crnn/parallel.py with CRNN.predict_lines as the recogniser: rank 0 and rank 1 of a world of two, each
+    with its own handle on the one GPU of this box, recognise their shards; the merged result is the oracle's strings
+    in input order (the gather is replaced by a list of the two ranks' parts: no process group is needed for that)."""
+    from oracle import oracle as orc
+    from ocr_amd.crnn.network_hip import CRNN
+    from ocr_amd.crnn.parallel import recognize_sharded
+    rs = np.random.RandomState(31)
+    widths = [int(w) for w in rs.choice(np.arange(24, 420, 4), size=60)] + [5, 8, 300, 300]
+    lines = [np.where(rs.rand(32, w) < 0.8, 200 + rs.randint(0, 50, (32, w)), rs.randint(0, 90, (32, w))).astype(np.uint8)
+             for w in widths]
+    want = [orc.predict_gray(oracle_en, ln, keys.alphabetEnglish) if ln.shape[1] >= 8 else "" for ln in lines]
+    models = []
+    for _ in range(2):
+        m = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish, device=0, lanes=2)
+        m.load_state_dict(synth_en)
+        models.append(m)
+    parts = [None, None]
+
+    def capture(rank):
+        def gather(part):
+            parts[rank] = part
+            return [part]                      # this rank's own view; the merge below uses both
+        return gather
+    for rank in range(2):
+        try:
+            recognize_sharded(models[rank].predict_lines, lines, widths, rank, 2, gather=capture(rank), max_batch=16)
+        except AssertionError:
+            pass                               # a single rank's part does not cover every line: expected here
+    assert parts[0] and parts[1] and not (set(parts[0]) & set(parts[1]))
+    assert sorted(set(parts[0]) | set(parts[1])) == list(range(len(lines)))
+    assert min(len(parts[0]), len(parts[1])) >= len(lines) // 4        # both ranks got real work
+    merged = recognize_sharded(models[0].predict_lines, lines, widths, 0, 2, gather=lambda part: [parts[0], parts[1]],
+                               max_batch=16)
+    assert merged == want
 
 
 @pytest.mark.gpu

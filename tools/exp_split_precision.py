@@ -36,8 +36,22 @@ def terms(n):
     return [(i, j) for i in range(3) for j in range(3) if i + j <= 2]
 
 
+def pow2_scale(t, target=2.0 ** 13):
+    """power of two s with max|t * s| in (target/2, target]: exact to apply and to undo"""
+    mx = float(t.abs().max())
+    return 2.0 ** np.floor(np.log2(target / mx)) if mx > 0 else 1.0
+
+
 def split_op(op, x, w):
-    n = 2 if MODE[1] == "3" else 3
+    n = 2 if MODE[-1] == "3" else 3
+    if MODE.startswith("hs"):                # fp16 with per-tensor power-of-two scaling (keeps the low parts normal)
+        sx, sw = pow2_scale(x), pow2_scale(w)
+        xs, ws = split(x * sx, 2), split(w * sw, 2)
+        out = None
+        for i, j in reversed(terms(2)):
+            t = op(xs[i], ws[j])
+            out = t if out is None else out + t
+        return out / (sx * sw)
     xs, ws = split(x, n), split(w, n)
     out = None
     for i, j in reversed(terms(n)):          # small terms first
