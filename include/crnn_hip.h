@@ -17,7 +17,8 @@
  * created lazily on the first call that needs it, so a handle may be created
  * before fork() (gunicorn preload_app, gunicorn.conf.py:57) and used after.
  *
- * Stream ordering of the device-pointer entry points (crnn_forward_device): the library queues its work on one of ITS OWN streams
+ * Stream ordering of the device-pointer entry points (crnn_forward_device and
+ * its _noalloc variant): the library queues its work on one of ITS OWN streams
  * (created non-blocking: no implicit ordering with the NULL stream or with a
  * framework's current stream).  Every input buffer must be completely written,
  * and every output buffer free to be overwritten, before the call is made --
@@ -158,6 +159,26 @@ CRNN_API int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t 
  * thread can order its own stream before that lane's stream (see "Stream ordering" above).  With several
  * threads calling crnn_forward_device on one handle the answer can be stale by the time it is used. */
 CRNN_API int crnn_next_lane(crnn_handle* h);
+
+/* crnn_forward_device for callers that must not allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, outputs and
+ * results as crnn_forward_device, but the whole activation workspace lives in a fixed array of the code object
+ * (CRNN_NOALLOC_SCRATCH_BYTES per GPU, held from module load until the process ends) and the call makes no
+ * hipMalloc / hipFree / hipHostMalloc and creates no stream or event: the handle's device state and weights must
+ * already be on the device (any earlier compute call on this handle in this process, or crnn_stream(h, 0) after
+ * crnn_load_weights); otherwise CRNN_ERR_STATE.  A batch whose workspace does not fit (about 4 lines of width
+ * 280 with the 5530-class head; crnn_noalloc_workspace_bytes tells) is refused with CRNN_ERR_ARG and a message
+ * naming the sizes.  All calls on one GPU share that GPU's array and are queued on lane 0's stream of their
+ * handle: calls through ONE handle are ordered by that stream; calls through different handles (or processes'
+ * threads using different handles) on the same GPU that overlap in time race on the array and must be
+ * serialised by the caller.  Nothing in the array has to start at zero (every kernel writes what it later reads),
+ * so a call is independent of what the previous one left there.  Returns 0 (the lane) or a negative status. */
+#define CRNN_NOALLOC_SCRATCH_BYTES (64u << 20)
+CRNN_API int crnn_forward_device_noalloc(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_t w,
+                                const int32_t* widths, int32_t* d_raw, int32_t* d_lab, int32_t* d_len,
+                                int32_t sync);
+/* Workspace bytes a batch of n lines of padded width w needs (what _noalloc compares with the limit). */
+CRNN_API int64_t crnn_noalloc_workspace_bytes(const crnn_handle* h, int32_t n, int32_t w);
 
 /* Number of times the hidden-split recurrence (small synchronous batches) gave up waiting for its partner
  * workgroups on this handle and the batch was repeated with the one-workgroup kernel (a latency cliff a

@@ -377,6 +377,17 @@ class CRNN(object):
                                            d_raw_ptr, d_lab_ptr, d_len_ptr, int(sync))
         return _capi.check(self._h, rc)
 
+    def forward_device_noalloc(self, d_gray_ptr, n, w, d_lab_ptr, d_len_ptr, d_raw_ptr=None, widths=None, sync=False):
+        """forward_device on the library's fixed workspace: makes no device allocation (for callers under HIP graph
+        capture or in loops that must not allocate).  Small batches only (crnn_noalloc_workspace_bytes); the device
+        state must exist already (stream_ptr(0) after the weights are loaded brings it up).  include/crnn_hip.h."""
+        wv = None
+        if widths is not None:
+            wv = np.ascontiguousarray(widths, dtype=np.int32)
+        rc = self._lib.crnn_forward_device_noalloc(self._h, d_gray_ptr, n, w, wv.ctypes.data if wv is not None else None,
+                                                   d_raw_ptr, d_lab_ptr, d_len_ptr, int(sync))
+        return _capi.check(self._h, rc)
+
     def synchronize(self):
         _capi.check(self._h, self._lib.crnn_synchronize(self._h))
 

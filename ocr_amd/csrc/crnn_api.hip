@@ -37,6 +37,16 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// Workspace of crnn_forward_device_noalloc (the entry point that must not allocate): a fixed array of the code
+// object.  In host code the array's NAME is only a stand-in for the symbol, not a device address: the address is
+// asked for once per device at set-up (ensure_device, with that device current; every GPU has its own copy at its
+// own address) and only that pointer is ever handed to kernels, memsets or copies.
+static __device__ __align__(256) unsigned char scratch[CRNN_NOALLOC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES] = {};      // [device ordinal] -> device address of `scratch` on that GPU (this process)
+pid_t g_scratch_pid[MAX_DEVICES] = {};
+std::mutex g_scratch_mu;
+
 constexpr int MAX_LANES = 8;
 constexpr int MAXK = 32;
 
@@ -123,6 +133,7 @@ struct crnn_handle {
   uint16_t* db_emb_w[2] = {};
   uint16_t* db_lin_w = nullptr;
   bool kprof = false;
+  void* scratch_ptr = nullptr;   // device address of the no-alloc workspace on cfg.device (set by ensure_device)
 
   // Lanes: independent (stream, workspace) pairs.  Successive crnn_forward_device calls go to
   // successive lanes, so the latency-bound LSTM recurrence of one batch (32 workgroups) runs
@@ -211,6 +222,7 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     h->dev_ready = false;
     h->weights_on_dev = false;
     h->split_ev = nullptr;
+    h->scratch_ptr = nullptr;
     for (Lane& L : h->lanes) {
       L.ev_valid = false;
       L.nk = 0;
@@ -226,6 +238,16 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       return fail(h, CRNN_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
     if (h->cfg.device < 0 || h->cfg.device >= ndev) return fail(h, CRNN_ERR_ARG, "device ordinal out of range");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->cfg.device < MAX_DEVICES) {   // once per device and process: where this GPU keeps its copy of `scratch`
+      std::lock_guard<std::mutex> lk(g_scratch_mu);
+      if (!g_scratch_ptr[h->cfg.device] || g_scratch_pid[h->cfg.device] != getpid()) {
+        void* ptr = nullptr;
+        HIPCHK(h, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[h->cfg.device] = ptr;
+        g_scratch_pid[h->cfg.device] = getpid();
+      }
+      h->scratch_ptr = g_scratch_ptr[h->cfg.device];
+    }
     for (int l = 0; l < h->nlanes; l++) {
       Lane& L = h->lanes[l];
       HIPCHK(h, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
@@ -1303,6 +1325,60 @@ int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_
     HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, tl_cur->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
   return lane;
+}
+
+int64_t crnn_noalloc_workspace_bytes(const crnn_handle* h, int32_t n, int32_t w) {
+  if (!h || n <= 0 || w < 8) return CRNN_ERR_ARG;
+  return (int64_t)make_plan(h, Geo(n, w), nullptr).bytes;
+}
+
+// crnn_forward_device on the fixed workspace: no hipMalloc / hipFree / hipHostMalloc, no stream or event creation.
+// Everything this function touches on the device was created by an earlier ensure_device(); the plan is carved
+// out of h->scratch_ptr (never out of the array's name) and the kernels get their pointers from the plan as usual.
+int crnn_forward_device_noalloc(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_t w, const int32_t* widths,
+                                int32_t* d_raw, int32_t* d_lab, int32_t* d_len, int32_t sync) {
+  if (!h) return CRNN_ERR_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!d_gray || n <= 0 || w < 8 || !d_lab || !d_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
+  if (widths)
+    for (int i = 0; i < n; i++)
+      if (widths[i] < 8 || widths[i] > w) return fail(h, CRNN_ERR_ARG, "line width outside [8, w]");
+  if (!h->dev_ready || h->dev_pid != getpid() || !h->weights_on_dev || !h->scratch_ptr)
+    return fail(h, CRNN_ERR_STATE,
+                "crnn_forward_device_noalloc: the device state of this handle does not exist yet in this process and "
+                "this entry point may not create it (it allocates): call crnn_stream(h, 0) after crnn_load_weights, or "
+                "any other compute entry point, once first");
+  const Geo g(n, w);
+  const double big = 4.0 * g.n * std::max(std::max(16.0 * g.W1 * 64, 8.0 * g.W2 * 256), 4.0 * g.W3 * 512);
+  const size_t need = big < 2147000000.0 ? make_plan(h, g, nullptr).bytes : (size_t)-1;
+  if (need > (size_t)CRNN_NOALLOC_SCRATCH_BYTES) {
+    char msg[256];
+    snprintf(msg, sizeof msg,
+             "crnn_forward_device_noalloc: %d lines of width %d need a workspace of %.1f MiB, the fixed one holds %.0f MiB: "
+             "use a smaller batch or crnn_forward_device", n, w, (double)need / 1048576.0,
+             (double)CRNN_NOALLOC_SCRATCH_BYTES / 1048576.0);
+    return fail(h, CRNN_ERR_ARG, msg);
+  }
+  tl_cur = &h->lanes[0];                                   // every no-alloc call is ordered on lane 0's stream
+  std::lock_guard<std::mutex> lane_lk(h->lanes[0].mu);
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const Plan p = make_plan(h, g, (char*)h->scratch_ptr);
+  hipStream_t s = tl_cur->stream;
+  int32_t* d_w = nullptr;
+  if (widths) {
+    d_w = p.wl + 4 * (size_t)n;
+    HIPCHK(h, hipMemcpyAsync(d_w, widths, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(h, hipEventRecord(tl_cur->ev[0], s));
+  tl_cur->nk = 0;
+  if (h->kprof) HIPCHK(h, hipEventRecord(tl_cur->kev[0], s));
+  launch_normalize(d_gray, p.x, d_w, n, w, w, s);
+  kmark(h, "normalize", 0, (double)n * 32 * w * 5.0);
+  int rc;
+  if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
+  if (d_raw) HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, s));
+  if (sync) HIPCHK(h, hipStreamSynchronize(s));
+  return 0;
 }
 
 int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const int32_t* widths, int32_t stage,
