@@ -90,6 +90,13 @@ struct crnn_handle {
   // wino_mask for batches of at least wino4_min_n lines; measured faster from one line up, so the default is 1)
   std::vector<float> h_wino4[7];
   unsigned wino4_mask = 0;
+  // f16x3 (CRNN_F16X3, default on; fp32 precision only): the Winograd GEMMs of the F(4x4) / F(4,2) layers run on the fp16
+  // MFMA with operands split into (hi, lo) fp16 pairs -- fp32-accurate products at 16/3 of the f32 MFMA rate
+  // (crnn_kernels.hip).  The weights are then kept only in that form: h_wino4h[i] + their unscale factor.
+  bool h3 = true;
+  std::vector<uint16_t> h_wino4h[7];
+  float wino4_us[7] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  uint16_t* d_wino4h[7] = {};
   int wino4_min_n = 1;
   // classifier arg-max through the certified bf16 pre-filter when the logits are not requested (fp32 path;
   // CRNN_CLS_FILTER=0: plain fp32 GEMM with the fused arg-max)
@@ -284,6 +291,8 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       if ((rc = upload(h, h->h_wino[i], &h->d_wino[i]))) return rc;
     for (int i = 0; i < 7; i++)
       if ((rc = upload(h, h->h_wino4[i], &h->d_wino4[i]))) return rc;
+    for (int i = 0; i < 7; i++)
+      if ((rc = upload16(h, h->h_wino4h[i], &h->d_wino4h[i]))) return rc;
     if ((rc = upload(h, h->h_cls_wnorm, &h->d_cls_wnorm))) return rc;
     for (int l = 0; l < 2; l++) {
       if ((rc = upload16(h, h->hb_wih[l], &h->db_wih[l]))) return rc;
@@ -365,6 +374,7 @@ struct Plan {
   float* anorm;   // [n*T] its row norms
   float* pmax;   // [n*T][n-tiles of the classifier]
   float *wv, *wm; // Winograd V[16][tiles][Cin] and Mo[16][tiles][Cout] (largest enabled layer)
+  float* vs;      // f16x3: per-tile unscale factors of the current layer's V (largest tile count)
   int32_t* pidx;
   size_t bytes;
 };
@@ -431,6 +441,13 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
     }
     p.wv = take(vmax);
     p.wm = take(mmax);
+    size_t tmax = 0;
+    if (use_wino4(h, (int)n)) {
+      const int hh[6] = {0, 16, 8, 8, 4, 4}, ww[6] = {0, g.W1, g.W2, g.W2, g.W3, g.W3};
+      for (int i = 1; i <= 5; i++) tmax = std::max(tmax, (size_t)wino4_pad(wino4_tiles((int)n, hh[i], ww[i])));
+      tmax = std::max(tmax, (size_t)wino4_pad((long)n * ((g.T + 3) / 4)));
+    }
+    p.vs = take(tmax);
   }
   p.bytes = off;
   return p;
@@ -475,10 +492,13 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
 // itself (one tile == one pool window).  Returns true when it did, so the caller skips the pool.
 bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
           int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr, float* pool_out = nullptr,
-          float* pool21_out = nullptr) {
+          float* pool21_out = nullptr, float* vs = nullptr) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   const bool b16 = h->cfg.precision == CRNN_BF16;
-  if (!b16 && ((h->wino4_mask >> layer) & 1u) && wino_v && wino_m && use_wino4(h, n)) {
+  // (with f16x3 weights only the split form of U exists: a shape that form does not take falls through to the direct conv)
+  const bool h3_ok = h->h3 && layer >= 1 && layer <= 5 && h->d_wino4h[layer] && vs && NM[layer] % 128 == 0 &&
+                     (Cin & (Cin - 1)) == 0 && Cin >= 64 && Cin <= 512;
+  if (!b16 && ((h->wino4_mask >> layer) & 1u) && wino_v && wino_m && use_wino4(h, n) && (h3_ok || h->d_wino4[layer])) {
     // Winograd F(4x4,3x3): input transform, 36 GEMMs (K = Cin) in one persistent launch, output transform
     static const char* wn4[3][7] = {{"", "conv1_win4", "conv2_win4", "conv3_win4", "conv4_win4", "conv5_win4", ""},
                                     {"", "conv1_f4", "conv2_f4", "conv3_f4", "conv4_f4", "conv5_f4", ""},
@@ -486,10 +506,12 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     const int Co = NM[layer];
     const long tiles = wino4_tiles(n, Hin, Win), tp = wino4_pad(tiles);
     hipStream_t s = tl_cur->stream;
-    launch_wino4_in((const float*)A, wino_v, n, Hin, Win, Cin, s);
+    const bool h3 = h3_ok;
+    launch_wino4_in((const float*)A, wino_v, n, Hin, Win, Cin, s, h3 ? vs : nullptr);
     kmark(h, wn4[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 36.0 * tiles * Cin));
     Wino4Gemm w{};
-    w.V = wino_v; w.U = h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co; w.Cin = Cin; w.ncomp = 36;
+    w.V = wino_v; w.U = h3 ? (const float*)h->d_wino4h[layer] : h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp;
+    w.N = Co; w.Cin = Cin; w.ncomp = 36; w.h3 = h3;
     launch_wino4_gemm(w, s);
     kmark(h, wn4[1][layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * 36 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
     static const bool fuse21 = !(getenv("CRNN_WINO4_POOL21") && atoi(getenv("CRNN_WINO4_POOL21")) == 0);
@@ -498,25 +520,29 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     if (!fuse21 || n < 128) pool21_out = nullptr;
     float* dst = pool_out ? pool_out : (pool21_out ? pool21_out : (float*)C);
     launch_wino4_out(wino_m, h->d_conv_b[layer], dst, wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1,
-                     pool_out ? 1 : (pool21_out ? 2 : 0), s);
+                     pool_out ? 1 : (pool21_out ? 2 : 0), s, h3 ? vs : nullptr, h->wino4_us[layer]);
     const double outpx = pool_out ? (double)n * (Hin / 2) * (Win / 2)
                                   : (pool21_out ? (double)n * (Hin / 2) * (Win + 1) : (double)n * Hin * Win);
     kmark(h, pool21_out ? (layer == 3 ? "conv3_wout4_pool2" : "conv5_wout4_pool3") : wn4[2][layer], 0,
           4.0 * (36.0 * tiles * Co + outpx * Co));
     return pool_out != nullptr || pool21_out != nullptr;
   }
-  if (!b16 && layer == 6 && h->wino6 && wino_v && wino_m && use_wino4(h, n)) {
+  const bool h3_ok6 = h->h3 && layer == 6 && h->d_wino4h[6] && vs && Cin == 512;
+  if (!b16 && layer == 6 && h->wino6 && wino_v && wino_m && use_wino4(h, n) && (h3_ok6 || h->d_wino4[6])) {
     // conv6 as 1-D Winograd F(4,2) along the width: 5 GEMMs of K = 2 Cin instead of one of K = 4 Cin
     const int Co = NM[6];
     const long tiles = (long)n * ((Wout + 3) / 4), tp = wino4_pad(tiles);
     hipStream_t s = tl_cur->stream;
-    launch_wino42_in((const float*)A, wino_v, n, Win, Cin, s);
+    const bool h3 = h3_ok6;
+    launch_wino42_in((const float*)A, wino_v, n, Win, Cin, s, h3 ? vs : nullptr);
     kmark(h, "conv6_win4", 0, 4.0 * ((double)n * 2 * Win * Cin + 5.0 * tiles * 2 * Cin));
     Wino4Gemm w{};
-    w.V = wino_v; w.U = h->d_wino4[6]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co; w.Cin = 2 * Cin; w.ncomp = 5;
+    w.V = wino_v; w.U = h3 ? (const float*)h->d_wino4h[6] : h->d_wino4[6]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co;
+    w.Cin = 2 * Cin; w.ncomp = 5; w.h3 = h3;
     launch_wino4_gemm(w, s);
     kmark(h, "conv6_f4", 2.0 * 5 * tiles * Co * 2 * Cin, 4.0 * 5 * ((double)tiles * 2 * Cin + (double)Co * 2 * Cin + (double)tiles * Co));
-    launch_wino42_out(wino_m, h->d_conv_b[6], (float*)C, n, Wout, Co, h->cfg.leaky_relu ? 2 : 1, s);
+    launch_wino42_out(wino_m, h->d_conv_b[6], (float*)C, n, Wout, Co, h->cfg.leaky_relu ? 2 : 1, s, h3 ? vs : nullptr,
+                      h->wino4_us[6]);
     kmark(h, "conv6_wout4", 0, 4.0 * (5.0 * tiles * Co + (double)n * Wout * Co));
     return false;
   }
@@ -597,24 +623,24 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   if (b16) launch_conv0_pool_bf16(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
   else launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
   kmark(h, "conv0_pool0", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * dn * 32 * g.W + es * dn * 16 * g.W1 * 64);
-  if (!conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1, p.wv, p.wm, p.p1)) {
+  if (!conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1, p.wv, p.wm, p.p1, nullptr, p.vs)) {
     if (b16) launch_pool_2x2s2_bf16(p.c1, p.p1, n, 16, g.W1, 128, s);
     else launch_pool_2x2s2(p.c1, p.p1, n, 16, g.W1, 128, s);
     kmark(h, "pool1", 0, es * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
   }
-  conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2, p.wv, p.wm);
-  if (!conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2, p.wv, p.wm, nullptr, p.p2)) {
+  conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2, p.wv, p.wm, nullptr, nullptr, p.vs);
+  if (!conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2, p.wv, p.wm, nullptr, p.p2, p.vs)) {
     if (b16) launch_pool_2x2s21p01_bf16(p.c3, p.p2, n, 8, g.W2, 256, s);
     else launch_pool_2x2s21p01(p.c3, p.p2, n, 8, g.W2, 256, s);
     kmark(h, "pool2", 0, es * (dn * 8 * g.W2 * 256 + dn * 4 * g.W3 * 256));
   }
-  conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3, p.wv, p.wm);
-  if (!conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3, p.wv, p.wm, nullptr, p.p3)) {
+  conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3, p.wv, p.wm, nullptr, nullptr, p.vs);
+  if (!conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3, p.wv, p.wm, nullptr, p.p3, p.vs)) {
     if (b16) launch_pool_2x2s21p01_bf16(p.c5, p.p3, n, 4, g.W3, 512, s);
     else launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
     kmark(h, "pool3", 0, es * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
   }
-  conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T, p.wv, p.wm);
+  conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T, p.wv, p.wm, nullptr, nullptr, p.vs);
   HIPCHK(h, hipEventRecord(tl_cur->ev[2], s));
   const int M = n * g.T;
   const double recflop = 2.0 * M * 2 * 1024 * 256;
@@ -848,6 +874,8 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   if (const char* e = getenv("CRNN_WINO4_MIN_N")) h->wino4_min_n = atoi(e);
   if (const char* e = getenv("CRNN_LIN_GEMM")) h->lin_gemm = atoi(e) != 0;
   if (const char* e = getenv("CRNN_WINO6")) h->wino6 = atoi(e) != 0;
+  if (const char* e = getenv("CRNN_F16X3")) h->h3 = atoi(e) != 0;
+  if (cfg->precision != CRNN_FP32) h->h3 = false;
   if (const char* e = getenv("CRNN_CLS_FILTER")) h->cls_filter = atoi(e) != 0;
   if (cfg->precision != CRNN_FP32) h->cls_filter = false;
   if (cfg->precision != CRNN_FP32) h->wino6 = false;
@@ -1004,6 +1032,13 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
         }
     }
   }
+  if (h->h3)
+    for (int i = 1; i <= 6; i++) {
+      if (h->h_wino4[i].empty()) continue;
+      h->h_wino4h[i].resize(h->h_wino4[i].size() * 2);
+      h->wino4_us[i] = to_f16x3_host(h->h_wino4[i].data(), h->h_wino4[i].size(), h->h_wino4h[i].data());
+      std::vector<float>().swap(h->h_wino4[i]);     // only the split form is used
+    }
   if (h->cfg.lstm) {
     for (int l = 0; l < 2; l++) {
       const int nin = l == 0 ? 512 : nh, nout = l == 0 ? nh : nclass;
@@ -1496,6 +1531,7 @@ void crnn_destroy(crnn_handle* h) {
     (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->db_lin_w); (void)hipFree(h->d_zero_bias);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4[i]);
+    for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4h[i]);
     (void)hipFree(h->d_cls_wnorm);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }

@@ -177,17 +177,23 @@ struct Wino4Gemm {
   float* M;         // [36][ntile_pad][N]
   int ntile_pad, N, Cin;
   int ncomp;        // number of component GEMMs: 36 (F(4x4,3x3)); 5 for conv6's 1-D F(4,2)
+  int h3;           // operands in the f16x3 format (crnn_kernels.hip): V and U hold (hi, lo) fp16 pairs, M leaves scaled
 };
 inline long wino4_tiles(int B, int H, int W) { return (long)B * (H / 4) * ((W + 3) / 4); }
 inline long wino4_pad(long tiles) { return (tiles + 127) / 128 * 128; }
-void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s);
+// vs != nullptr: V in the f16x3 format, vs[tile] = 1 / (the tile's scale)
+void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s, float* vs = nullptr);
 // conv6 as 1-D F(4,2): x NHWC [B,2,W,C] -> V[5][pad(B*ceil((W-1)/4))][2*C]; M[5][..][Cout] -> y [B*(W-1)][Cout] + bias, act
-void launch_wino42_in(const float* x, float* V, int B, int W, int C, hipStream_t s);
-void launch_wino42_out(const float* M, const float* bias, float* y, int B, int T, int Cout, int act, hipStream_t s);
+void launch_wino42_in(const float* x, float* V, int B, int W, int C, hipStream_t s, float* vs = nullptr);
+void launch_wino42_out(const float* M, const float* bias, float* y, int B, int T, int Cout, int act, hipStream_t s,
+                       const float* vs = nullptr, float us = 1.f);
 void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s);
 // pool: 0 none; 1 MaxPool 2x2/2 (y [B,H/2,W/2,Cout]); 2 MaxPool (2,2)/(2,1)/pad (0,1) (y [B,H/2,W+1,Cout])
+// vs / us: unscale factors of f16x3 products (per tile, per layer) or nullptr / 1
 void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
-                      int Cout, int act, int pool, hipStream_t s);
+                      int Cout, int act, int pool, hipStream_t s, const float* vs = nullptr, float us = 1.f);
+// host: rows of K floats -> the f16x3 format with ONE scale for the whole tensor; returns 1 / scale
+float to_f16x3_host(const float* src, size_t n, uint16_t* dst /* 2 n halves */);
 
 // conv0 (1->64, 3x3, pad 1) + ReLU + MaxPool 2x2/2, direct (K = 9, HBM-bound).
 // in f32 [B,32,W]; out NHWC [B,16,W/2,64]; w1valid: per-sample valid pooled width or nullptr.

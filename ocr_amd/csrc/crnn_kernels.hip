@@ -8,6 +8,9 @@
 // chain), byte/integer work is plain coalesced vector code.
 #include "crnn_kernels.h"
 
+#include <cmath>
+#include <cstring>
+
 namespace crnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -772,6 +775,122 @@ __device__ __forceinline__ void wino4_at(const f32x4 (&m)[6], f32x4 (&r)[4]) {
   r[3] = d12 + 8.f * m[3] - 0.125f * m[4] + m[5];
 }
 
+// ---------------------------------------------------------------------------
+// "f16x3" operand format (CRNN_F16X3, default on): fp32-accurate GEMMs on the fp16 MFMA.  Every fp32 operand x of a GEMM
+// row is stored as two fp16 numbers hi = fp16(x s), lo = fp16(x s - hi) -- together 22 significant bits, the
+// representation error 2^-23 |x| is below fp32's own rounding -- with s a power of two per ROW (per Winograd tile /
+// per GEMM row) that puts the row's largest magnitude in [2^14, 2^15), so lo stays a normal fp16 down to 2^-15 of
+// the row's maximum (below that its absolute error, 2^-38 of the maximum, is far under the fp32 rounding of the
+// row's larger terms).  Layout: per 8 consecutive k, 8 hi then 8 lo (32 bytes: the bytes of 8 floats), so a row
+// is as long as its fp32 form and the 16-byte chunks of a K = 32 step are hi(k0-7) lo(k0-7) hi(k8-15) ...
+// The GEMM then computes hi_a hi_b + hi_a lo_b + lo_a hi_b (the dropped lo lo term is 2^-24 relative) with three
+// v_mfma_f32_32x32x16_f16 per fragment pair, fp32 accumulate, at 16x the f32 MFMA rate; the consumer of the
+// product multiplies by 1 / (s_row s_weights) (powers of two: exact).  Measured against float64 the result is as
+// accurate as the f32 MFMA's or better (fewer roundings: 16 products are summed per instruction; tools/split_mfma_test.hip).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void split_scale_from_max(float mx, float& s, float& uns) {
+  unsigned eb = (__builtin_bit_cast(unsigned, mx) >> 23) & 0xFFu;   // biased exponent of the row's largest magnitude
+  eb = eb < 32u ? 32u : (eb > 250u ? 250u : eb);                    // all-zero / tiny rows, infinities: keep s finite
+  s = __builtin_bit_cast(float, (268u - eb) << 23);                 // 2^(14 - E): max * s in [2^14, 2^15)
+  uns = __builtin_bit_cast(float, (eb - 14u) << 23);                // 1 / s
+}
+// four scaled values -> 4 hi and 4 lo halves (8 bytes each)
+__device__ __forceinline__ void split4(f32x4 v, float s, uint2& hi, uint2& lo) {
+  union { _Float16 h[4]; uint2 u; } ph, pl;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const float x = v[e] * s;
+    ph.h[e] = (_Float16)x;
+    pl.h[e] = (_Float16)(x - (float)ph.h[e]);
+  }
+  hi = ph.u;
+  lo = pl.u;
+}
+// lanes 2i / 2i+1 hold channels [8g, 8g+4) / [8g+4, 8g+8) of one row: the even lane stores the 16-byte hi chunk, the
+// odd lane the 16-byte lo chunk (one 16-byte store per lane, as in the fp32 form)
+__device__ __forceinline__ void store_split_pair(float* rowbase, int c4, uint2 hi, uint2 lo) {
+  const bool odd = c4 & 1;
+  const uint2 send = odd ? hi : lo;
+  uint2 recv;
+  recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
+  recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+  const uint4 out = odd ? uint4{recv.x, recv.y, lo.x, lo.y} : uint4{hi.x, hi.y, recv.x, recv.y};
+  *(uint4*)(rowbase + (c4 >> 1) * 8 + (odd ? 4 : 0)) = out;
+}
+
+// F(4x4,3x3) input transform writing the f16x3 format: as wino4_in_kernel, plus the tile's scale (the largest |v| over
+// its 36 components and all channels: the C/4 threads of a tile are consecutive lanes, or two waves for C = 512) to
+// vs[tile] (as 1 / s).  The block-level loop bound is uniform, so every thread reaches the barrier.
+__global__ __launch_bounds__(256) void wino4_in_h3_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                          float* __restrict__ vs, int B, int H, int W, int C,
+                                                          long ntile_pad) {
+  __shared__ float wmax[2][4];
+  const int th = H >> 2, tw = (W + 3) >> 2, C4 = C >> 2;
+  const long total = (long)B * th * tw * C4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  int par = 0;
+  for (long base = (long)blockIdx.x * blockDim.x; base < total; base += (long)gridDim.x * blockDim.x, par ^= 1) {
+    const long i = base + threadIdx.x;
+    const bool valid = i < total;       // uniform per tile (C4 divides 256 and total)
+    const long ii = valid ? i : 0;
+    const int c4 = (int)(ii % C4);
+    const long t = ii / C4;
+    const int tx = (int)(t % tw);
+    const long r = t / tw;
+    const int ty = (int)(r % th);
+    const int b = (int)(r / th);
+    f32x4 u[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const int xx = 4 * tx - 1 + j;
+      const bool okx = (unsigned)xx < (unsigned)W;
+      const float* px = x + ((long)b * H * W + (okx ? xx : 0)) * C + c4 * 4;
+      f32x4 d[6], c[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int yy = 4 * ty - 1 + k;
+        const bool ok = valid && okx && (unsigned)yy < (unsigned)H;
+        d[k] = ok ? *(const f32x4*)(px + (long)yy * W * C) : z;
+      }
+      wino4_bt(d, c);
+#pragma unroll
+      for (int k = 0; k < 6; k++) u[k][j] = c[k];
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      f32x4 v[6];
+      wino4_bt(u[k], v);
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        u[k][j] = v[j];
+#pragma unroll
+        for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_fabsf(v[j][e]));
+      }
+    }
+    for (int off = 1; off < C4 && off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (C4 > 64) {   // C = 512: a tile is two waves (wave pairs 0/1 and 2/3 of the block)
+      const int wave = threadIdx.x >> 6;
+      if ((threadIdx.x & 63) == 0) wmax[par][wave] = mx;
+      __syncthreads();
+      mx = fmaxf(mx, wmax[par][wave ^ 1]);
+    }
+    float sc, uns;
+    split_scale_from_max(mx, sc, uns);
+    if (valid) {
+      if (c4 == 0) vs[t] = uns;
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          uint2 hi, lo;
+          split4(u[k][j], sc, hi, lo);
+          store_split_pair(V + ((long)(k * 6 + j) * ntile_pad + t) * C, c4, hi, lo);
+        }
+    }
+  }
+}
+
 // One thread per (tile, 4 channels): 36 float4 loads (the 6x6 patch; neighbours' overlaps are L1/L2 hits),
 // columns then rows of B^T d B, 36 float4 stores.
 __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__ x, float* __restrict__ V,
@@ -816,10 +935,11 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__
 
 // One thread per (tile, 4 output channels): 36 float4 loads, A^T m A, bias + activation + width mask,
 // 16 float4 stores (or the 4 maxima of the 2x2 pool windows inside the tile).
+// vs / us (f16x3 GEMMs): the products are scaled by s_tile s_weights; vs[tile] = 1 / s_tile, us = 1 / s_weights (powers of two)
 __global__ __launch_bounds__(256) void wino4_out_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
                                                         float* __restrict__ y, const int32_t* __restrict__ wvalid,
                                                         int B, int H, int W, int Co, int act, int pool,
-                                                        long ntile_pad) {
+                                                        long ntile_pad, const float* __restrict__ vs, float us) {
   const int th = H >> 2, tw = (W + 3) >> 2, C4 = Co >> 2;
   const long total = (long)B * th * tw * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -841,6 +961,7 @@ __global__ __launch_bounds__(256) void wino4_out_kernel(const float* __restrict_
     }
     const f32x4 bs = *(const f32x4*)(bias + c4 * 4);
     const int wv = wvalid ? wvalid[b] : W;
+    const float rs = vs ? vs[t] * us : 1.f;
     f32x4 o[4][4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -848,7 +969,7 @@ __global__ __launch_bounds__(256) void wino4_out_kernel(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int xx = 4 * tx + j;
-        f32x4 v = o[k][j] + bs;
+        f32x4 v = o[k][j] * rs + bs;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           float e = v[c];
@@ -893,7 +1014,8 @@ __global__ __launch_bounds__(256) void wino4_out_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void wino4_out_pool21_kernel(const float* __restrict__ Mo,
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                const int32_t* __restrict__ wvalid, int B, int H, int W,
-                                                               int Co, int act, long ntile_pad, int nseg) {
+                                                               int Co, int act, long ntile_pad, int nseg,
+                                                               const float* __restrict__ vs, float us) {
   const int th = H >> 2, tw = (W + 3) >> 2, C4 = Co >> 2, Wp = W + 1, Hp = H >> 1;
   const int seglen = (tw + nseg - 1) / nseg;
   const long total = (long)B * th * nseg * C4;
@@ -913,6 +1035,7 @@ __global__ __launch_bounds__(256) void wino4_out_pool21_kernel(const float* __re
     for (int tx = tx0 > 0 ? tx0 - 1 : 0; tx < tx1; tx++) {
       const bool emit = tx >= tx0;
       const long t = ((long)b * th + ty) * tw + tx;
+      const float rs = vs ? vs[t] * us : 1.f;
       // all 36 loads first (few threads, each walking a row: the memory parallelism has to come from inside a thread)
       f32x4 mm[6][6];
 #pragma unroll
@@ -936,7 +1059,7 @@ __global__ __launch_bounds__(256) void wino4_out_pool21_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int xx = 4 * tx + j;
-          f32x4 v = o[j] + bs;
+          f32x4 v = o[j] * rs + bs;
 #pragma unroll
           for (int c = 0; c < 4; c++) {
             float e = v[c];
@@ -1311,6 +1434,159 @@ __global__ __launch_bounds__(576, 1) void wino4_gemm_lw_kernel(const Wino4Gemm p
   if (it + 1 < nit) step(std::integral_constant<int, 1>{});
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// ---------------------------------------------------------------------------
+// The Winograd component GEMMs on operands in the f16x3 format (see wino4_in_h3_kernel): same persistent balanced-unit
+// structure, unit order, three-stage direct-to-LDS pipeline, LDS layout and swizzle as wino4_gemm_kernel<4> -- a row's
+// K = 32 step is still 128 bytes = 8 chunks of 16 bytes, now hi(k0-7) lo(k0-7) hi(k8-15) lo(k8-15) ... -- but a K step
+// is two k16 MFMA steps of three products each (lo hi, hi lo, hi hi into one accumulator): 12 MFMAs of 32 cycles per wave
+// and K step instead of 32 of 64.  The products leave scaled by s_tile s_weights; the output transform undoes that.
+// 128 x 128 units, 8 waves as 2 (M) x 4 (N), wave tile 64 x 32; every wave issues its share of the loads (2 + 2 per step).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void wino4_gemm_h3_kernel(const Wino4Gemm p) {
+  constexpr int NWN = 4, NT = 512, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32, NLA = 2;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
+  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  unsigned aoff[NLA], boff[2];
+#pragma unroll
+  for (int i = 0; i < NLA; i++) {
+    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+    aoff[i] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
+    boff[i] = aoff[i];
+  }
+  const int nk = p.Cin / BK;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;
+  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  };
+  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) __attribute__((always_inline)) {
+    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
+    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.Cin * 4ull;
+    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.Cin * 4ull;
+    m = (unsigned long long)p.M +
+        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
+  };
+  int l_u = L, l_k0 = 0;
+  unsigned long long pa, pb, pm_unused;
+  bases(l_u, pa, pb, pm_unused);
+  auto gload = [&](int stage) __attribute__((always_inline)) {
+    const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+    const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+    const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
+#pragma unroll
+    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], l_k0 * 4);
+#pragma unroll
+    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * NT * 16, boff[i], l_k0 * 4);
+    l_k0 += BK;
+    if (l_k0 == p.Cin) {
+      l_k0 = 0;
+      if (l_u + G < NU) l_u += G;
+      unsigned long long pm;
+      bases(l_u, pa, pb, pm);
+    }
+  };
+  // fragment addresses (floats inside a stage): chunk c of row R sits at (R >> 1) * 64 + ((((R & 1) << 3) | c) ^ ((R >> 1) & 15)) * 4;
+  // k16-step j of a K = 32 step: hi = chunk 4 j + 2 h, lo = the chunk after it (h = lane >> 5)
+  int ahi[2], alo[2], bhi[2], blo[2];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = 4 * j + 2 * h;
+      ahi[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | c) ^ ((Ra >> 1) & 15)) << 2);
+      alo[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (c + 1)) ^ ((Ra >> 1) & 15)) << 2);
+      bhi[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | c) ^ ((Rb >> 1) & 15)) << 2);
+      blo[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (c + 1)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+  int kc = 0, c_u = L;
+  const unsigned moff = (unsigned)((wm * 64 + (lane & 31)) * p.N + wn * 32 + 4 * (lane >> 5));
+  auto flush = [&]() __attribute__((always_inline)) {
+    unsigned long long ua, ub, pm;
+    bases(c_u, ua, ub, pm);
+    typedef __attribute__((address_space(1))) f32x4 gf32x4;
+    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+        *(gf32x4*)(dst + mt * 32 * p.N + 8 * g) = v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[mt][4 * g + e] = 0.f;
+      }
+    kc = 0;
+    c_u += G;
+  };
+  f16x8 a0h[2], a0l[2], a1h[2], a1l[2], bh[2], bl[2];
+  auto frag = [&](int stage, int j, int set) __attribute__((always_inline)) {
+    const float* sa = smem + 3 * SB + stage * SA;
+    const float* sb = smem + stage * SB;
+    a0h[set] = *(const f16x8*)(sa + ahi[j]);
+    a0l[set] = *(const f16x8*)(sa + alo[j]);
+    a1h[set] = *(const f16x8*)(sa + ahi[j] + 1024);
+    a1l[set] = *(const f16x8*)(sa + alo[j] + 1024);
+    bh[set] = *(const f16x8*)(sb + bhi[j]);
+    bl[set] = *(const f16x8*)(sb + blo[j]);
+  };
+  auto mfma6 = [&](int set) __attribute__((always_inline)) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[set], a0h[set], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[set], a1h[set], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a0l[set], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a1l[set], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a0h[set], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a1h[set], acc[1], 0, 0, 0);
+  };
+  auto step = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
+    frag(st, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // vmcnt(one step's loads), lgkmcnt(0)
+    __syncthreads();
+    gload(st);
+    frag(nx, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kc == nk) flush();
+  };
+  const int nit = my_units * nk;
+  gload(0);
+  gload(1);
+  gload(2);
+  constexpr int LPS = NLA + 2;
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));
+  __syncthreads();
+  frag(0, 0, 0);
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
+
 // ---------------------------------------------------------------------------
 // Plain GEMM C = act(A W^T + bias) on the same persistent direct-to-LDS pipeline (LSTM input projections and
 // the classifier: M = lines x T rows, K = 256 / 512).  Units of 128 x 128, unit u = m-tile * ntn + n-tile,
@@ -1575,27 +1851,36 @@ void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
   const int slots = nwn == 2 ? 512 : 256;
   const int g = units < slots ? 8 * ((units + 7) / 8) : slots;
   static const int lw = getenv("CRNN_WINO4_LW") ? atoi(getenv("CRNN_WINO4_LW")) : 1;
+  if (p.h3) {   // operands in the f16x3 format (N % 128 == 0 checked by the caller)
+    const int u3 = p.ncomp * (p.ntile_pad / 128) * (p.N / 128);
+    hipLaunchKernelGGL(wino4_gemm_h3_kernel, dim3(u3 < 256 ? 8 * ((u3 + 7) / 8) : 256), dim3(512), 0, s, p);
+    return;
+  }
   if (nwn == 2) hipLaunchKernelGGL((wino4_gemm_kernel<2>), dim3(g), dim3(256), 0, s, p);
   else if (lw) hipLaunchKernelGGL(wino4_gemm_lw_kernel, dim3(g), dim3(576), 0, s, p);
   else hipLaunchKernelGGL((wino4_gemm_kernel<4>), dim3(g), dim3(512), 0, s, p);
 }
-void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s) {
+void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s, float* vs) {
   const long total = wino4_tiles(B, H, W) * (C / 4);
-  hipLaunchKernelGGL(wino4_in_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, x, V, B, H, W, C,
-                     wino4_pad(wino4_tiles(B, H, W)));
+  if (vs)   // f16x3 format + per-tile scales; C / 4 must divide 256 (C = 64 ... 512, a power of two)
+    hipLaunchKernelGGL(wino4_in_h3_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, x, V, vs, B, H, W, C,
+                       wino4_pad(wino4_tiles(B, H, W)));
+  else
+    hipLaunchKernelGGL(wino4_in_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, x, V, B, H, W, C,
+                       wino4_pad(wino4_tiles(B, H, W)));
 }
 void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
-                      int Cout, int act, int pool, hipStream_t s) {
+                      int Cout, int act, int pool, hipStream_t s, const float* vs, float us) {
   if (pool == 2) {
     const int tw = (W + 3) / 4, nseg = tw >= 16 ? tw / 8 : 1;   // segments of 8-9 tiles (one extra tile of work each)
     const long rows = (long)B * (H / 4) * nseg * (Cout / 4);
     hipLaunchKernelGGL(wino4_out_pool21_kernel, dim3(ew_blocks_w(rows)), dim3(256), 0, s, M, bias, y, wvalid, B, H, W,
-                       Cout, act, wino4_pad(wino4_tiles(B, H, W)), nseg);
+                       Cout, act, wino4_pad(wino4_tiles(B, H, W)), nseg, vs, us);
     return;
   }
   const long total = wino4_tiles(B, H, W) * (Cout / 4);
   hipLaunchKernelGGL(wino4_out_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, M, bias, y, wvalid, B, H, W, Cout,
-                     act, pool, wino4_pad(wino4_tiles(B, H, W)));
+                     act, pool, wino4_pad(wino4_tiles(B, H, W)), vs, us);
 }
 
 // ---------------------------------------------------------------------------
@@ -1639,9 +1924,63 @@ __global__ __launch_bounds__(256) void wino42_in_kernel(const float* __restrict_
   }
 }
 
+// f16x3 form of the input transform: a row of V6 is one tile (both kernel rows, all channels): with C = 512 that is
+// exactly one 256-thread block iteration, so the row's scale is a block-wide maximum.
+__global__ __launch_bounds__(256) void wino42_in_h3_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                           float* __restrict__ vs, int B, int W, int C, long ntile_pad) {
+  __shared__ float wmax[2][4];
+  const int T = W - 1, tw = (T + 3) >> 2, C4 = C >> 2;   // 2 * C4 == 256
+  const long total = (long)B * tw * 2 * C4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  int par = 0;
+  for (long base = (long)blockIdx.x * blockDim.x; base < total; base += (long)gridDim.x * blockDim.x, par ^= 1) {
+    const long i = base + threadIdx.x;     // total is a multiple of 256: every thread of the block is valid
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int ky = (int)(r & 1);
+    r >>= 1;
+    const int tx = (int)(r % tw);
+    const int b = (int)(r / tw);
+    const float* px = x + (((long)b * 2 + ky) * W) * C + c4 * 4;
+    f32x4 d[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int xx = 4 * tx + j;
+      d[j] = xx < W ? *(const f32x4*)(px + (long)xx * C) : z;
+    }
+    const f32x4 d31 = d[3] - d[1];
+    f32x4 v[5];
+    v[0] = 2.f * (d[0] - d[2]) + d31;
+    v[1] = d[3] - d[2] - 2.f * d[1];
+    v[2] = 2.f * d[1] - 3.f * d[2] + d[3];
+    v[3] = d31;
+    v[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_fabsf(v[k][e]));
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) wmax[par][threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wmax[par][0], wmax[par][1]), fmaxf(wmax[par][2], wmax[par][3]));
+    float sc, uns;
+    split_scale_from_max(mx, sc, uns);
+    const long t = (long)b * tw + tx;
+    if (threadIdx.x == 0) vs[t] = uns;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      uint2 hi, lo;
+      split4(v[k], sc, hi, lo);
+      store_split_pair(V + (long)k * ntile_pad * 2 * C + (t * 2 + ky) * C, c4, hi, lo);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wino42_out_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
                                                          float* __restrict__ y, int B, int T, int Co, int act,
-                                                         long ntile_pad) {
+                                                         long ntile_pad, const float* __restrict__ vs, float us) {
   const int tw = (T + 3) >> 2, C4 = Co >> 2;
   const long total = (long)B * tw * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1653,6 +1992,7 @@ __global__ __launch_bounds__(256) void wino42_out_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < 5; k++) m[k] = *(const f32x4*)(Mo + ((long)k * ntile_pad + t) * Co + c4 * 4);
     const f32x4 bs = *(const f32x4*)(bias + c4 * 4);
+    const float rs = vs ? vs[t] * us : 1.f;
     const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2];
     f32x4 o[4];
     o[0] = m[0] + s12 + m[3];
@@ -1663,7 +2003,7 @@ __global__ __launch_bounds__(256) void wino42_out_kernel(const float* __restrict
     for (int j = 0; j < 4; j++) {
       const int xx = 4 * tx + j;
       if (xx >= T) continue;
-      f32x4 v = o[j] + bs;
+      f32x4 v = o[j] * rs + bs;
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         float e = v[c];
@@ -1676,15 +2016,20 @@ __global__ __launch_bounds__(256) void wino42_out_kernel(const float* __restrict
   }
 }
 
-void launch_wino42_in(const float* x, float* V, int B, int W, int C, hipStream_t s) {
+void launch_wino42_in(const float* x, float* V, int B, int W, int C, hipStream_t s, float* vs) {
   const long tiles = (long)B * ((W - 1 + 3) / 4);
-  hipLaunchKernelGGL(wino42_in_kernel, dim3(ew_blocks_w(tiles * 2 * (C / 4))), dim3(256), 0, s, x, V, B, W, C,
-                     wino4_pad(tiles));
+  if (vs && C == 512)
+    hipLaunchKernelGGL(wino42_in_h3_kernel, dim3(ew_blocks_w(tiles * 2 * (C / 4))), dim3(256), 0, s, x, V, vs, B, W, C,
+                       wino4_pad(tiles));
+  else
+    hipLaunchKernelGGL(wino42_in_kernel, dim3(ew_blocks_w(tiles * 2 * (C / 4))), dim3(256), 0, s, x, V, B, W, C,
+                       wino4_pad(tiles));
 }
-void launch_wino42_out(const float* M, const float* bias, float* y, int B, int T, int Cout, int act, hipStream_t s) {
+void launch_wino42_out(const float* M, const float* bias, float* y, int B, int T, int Cout, int act, hipStream_t s,
+                       const float* vs, float us) {
   const long tiles = (long)B * ((T + 3) / 4);
   hipLaunchKernelGGL(wino42_out_kernel, dim3(ew_blocks_w(tiles * (Cout / 4))), dim3(256), 0, s, M, bias, y, B, T, Cout,
-                     act, wino4_pad(tiles));
+                     act, wino4_pad(tiles), vs, us);
 }
 
 // ---------------------------------------------------------------------------
@@ -2564,6 +2909,22 @@ void launch_resize_v(const uint8_t* /*src*/, const ResizeJob* jobs, const int32_
                      const uint8_t* tmp, float* out, int n, int Wp, hipStream_t s) {
   hipLaunchKernelGGL(resize_v_kernel, dim3((Wp + 255) / 256, 32, n), dim3(256), 0, s, jobs, coef, tmp,
                      out, Wp);
+}
+
+float to_f16x3_host(const float* src, size_t n, uint16_t* dst) {
+  float mx = 0.f;
+  for (size_t i = 0; i < n; i++) mx = fmaxf(mx, fabsf(src[i]));
+  int e = 0;
+  if (mx > 0.f && std::isfinite(mx)) (void)frexpf(mx, &e);   // mx = f 2^e, f in [0.5, 1): floor(log2 mx) = e - 1
+  const float s = ldexpf(1.f, 14 - (e - 1)), uns = ldexpf(1.f, (e - 1) - 14);
+  for (size_t i = 0; i < n; i++) {
+    const float x = src[i] * s;
+    const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+    const size_t blk = i / 8, k = i % 8;
+    memcpy(dst + blk * 16 + k, &hi, 2);
+    memcpy(dst + blk * 16 + 8 + k, &lo, 2);
+  }
+  return uns;
 }
 
 void upload_norm_lut(const float* lut256, hipStream_t s) {
