@@ -416,7 +416,7 @@ class CRNN(object):
 
     def kernel_times(self):
         """[(name, ms, flops, bytes)] per launch of the most recent forward_device (profiling on)."""
-        cap = 32
+        cap = 48
         names = (C.c_char_p * cap)()
         ms = (C.c_float * cap)()
         fl = (C.c_double * cap)()

@@ -48,7 +48,7 @@ pid_t g_scratch_pid[MAX_DEVICES] = {};
 std::mutex g_scratch_mu;
 
 constexpr int MAX_LANES = 8;
-constexpr int MAXK = 32;
+constexpr int MAXK = 48;
 
 struct Lane {
   hipStream_t stream = nullptr;
@@ -97,6 +97,11 @@ struct crnn_handle {
   std::vector<uint16_t> h_wino4h[7];
   float wino4_us[7] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   uint16_t* d_wino4h[7] = {};
+  // ... and the LSTM input projections and the first embedding (lin_gemm_h3_kernel): W in the split form + unscale factor
+  std::vector<uint16_t> h_wih_h3[2], h_emb0_h3;
+  float wih_us[2] = {1.f, 1.f}, emb0_us = 1.f;
+  uint16_t* d_wih_h3[2] = {};
+  uint16_t* d_emb0_h3 = nullptr;
   int wino4_min_n = 1;
   // classifier arg-max through the certified bf16 pre-filter when the logits are not requested (fp32 path;
   // CRNN_CLS_FILTER=0: plain fp32 GEMM with the fused arg-max)
@@ -293,6 +298,9 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       if ((rc = upload(h, h->h_wino4[i], &h->d_wino4[i]))) return rc;
     for (int i = 0; i < 7; i++)
       if ((rc = upload16(h, h->h_wino4h[i], &h->d_wino4h[i]))) return rc;
+    for (int l = 0; l < 2; l++)
+      if ((rc = upload16(h, h->h_wih_h3[l], &h->d_wih_h3[l]))) return rc;
+    if ((rc = upload16(h, h->h_emb0_h3, &h->d_emb0_h3))) return rc;
     if ((rc = upload(h, h->h_cls_wnorm, &h->d_cls_wnorm))) return rc;
     for (int l = 0; l < 2; l++) {
       if ((rc = upload16(h, h->hb_wih[l], &h->db_wih[l]))) return rc;
@@ -375,6 +383,7 @@ struct Plan {
   float* pmax;   // [n*T][n-tiles of the classifier]
   float *wv, *wm; // Winograd V[16][tiles][Cin] and Mo[16][tiles][Cout] (largest enabled layer)
   float* vs;      // f16x3: per-tile unscale factors of the current layer's V (largest tile count)
+  float *a3, *rs; // f16x3 copy of a plain GEMM's A operand [n*T][512] and its per-128-row unscale factors
   int32_t* pidx;
   size_t bytes;
 };
@@ -448,6 +457,8 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
       tmax = std::max(tmax, (size_t)wino4_pad((long)n * ((g.T + 3) / 4)));
     }
     p.vs = take(tmax);
+    p.a3 = take(h->h3 && h->cfg.lstm ? n * g.T * 512 : 0);
+    p.rs = take(h->h3 && h->cfg.lstm ? (n * g.T + 127) / 128 : 0);
   }
   p.bytes = off;
   return p;
@@ -473,9 +484,22 @@ static bool use_lin_gemm(const crnn_handle* h, const ConvGemm& p) {
 // out_bf16 only matters on the bf16 path (which GEMM outputs feed another GEMM)
 void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, const uint16_t* Wt16,
           const float* bias, void* C, int M, int N, int K, bool out_bf16, float* pmax = nullptr,
-          int32_t* pidx = nullptr) {
+          int32_t* pidx = nullptr, const uint16_t* W3 = nullptr, float us3 = 1.f, float* a3 = nullptr, float* rs = nullptr) {
   const bool b16 = h->cfg.precision == CRNN_BF16;
   ConvGemm p{};
+  if (!b16 && h->h3 && W3 && a3 && rs && !pmax && C && (K == 256 || K == 512) && N >= 256 && h->lin_gemm) {
+    // f16x3: convert the rows of A (one scale per 128-row block), then the GEMM on the fp16 MFMA
+    ConvGemm q{};
+    q.A = a3; q.Wt = (const float*)W3; q.bias = bias; q.C = (float*)C; q.M = M; q.N = N; q.K = K; q.ldc = N;
+    q.Hin = q.Win = q.Hout = q.Wout = 1; q.Cin = K; q.ks = 1; q.h3 = 1; q.rs = rs; q.us = us3;
+    if (lin_gemm_ok(q) && launch_rows_to_f16x3((const float*)A, a3, rs, M, K, tl_cur->stream)) {
+      static const char* cname[3] = {"lstm0_ih_split", "emb0_split", "lstm1_ih_split"};
+      kmark(h, cname[name[0] == 'e' ? 1 : (name[4] == '0' ? 0 : 2)], 0, 8.0 * M * K);
+      launch_lin_gemm(q, tl_cur->stream);
+      kmark(h, name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+      return;
+    }
+  }
   p.A = (const float*)A; p.Wt = b16 ? (const float*)Wt16 : Wt; p.bias = bias; p.C = (float*)C; p.wvalid = nullptr;
   p.M = M; p.N = N; p.K = K; p.ldc = N;
   p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = K; p.ks = 1; p.pad = 0; p.act = 0;
@@ -691,10 +715,13 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     return false;
   };
   if (h->cfg.lstm) {
-    gemm(h, "lstm0_ih", p.seq, h->d_wih[0], h->db_wih[0], h->d_bih[0], p.xp, M, 2048, 512, false);
+    gemm(h, "lstm0_ih", p.seq, h->d_wih[0], h->db_wih[0], h->d_bih[0], p.xp, M, 2048, 512, false, nullptr, nullptr,
+         h->d_wih_h3[0], h->wih_us[0], p.a3, p.rs);
     rec(0, p.rec0);
-    gemm(h, "emb0", p.rec0, h->d_emb_w[0], h->db_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512, true);
-    gemm(h, "lstm1_ih", p.mid, h->d_wih[1], h->db_wih[1], h->d_bih[1], p.xp, M, 2048, 256, false);
+    gemm(h, "emb0", p.rec0, h->d_emb_w[0], h->db_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512, true, nullptr, nullptr,
+         h->d_emb0_h3, h->emb0_us, p.a3, p.rs);
+    gemm(h, "lstm1_ih", p.mid, h->d_wih[1], h->db_wih[1], h->d_bih[1], p.xp, M, 2048, 256, false, nullptr, nullptr,
+         h->d_wih_h3[1], h->wih_us[1], p.a3, p.rs);
     rec(1, p.rec1);
     filtered = classify(p.rec1, h->d_emb_w[1], h->db_emb_w[1], h->d_emb_b[1]);
   } else {
@@ -1073,6 +1100,14 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
     if (!lb) return fail(h, CRNN_ERR_ARG, err);
     h->h_lin_w.assign(lw, lw + (size_t)nclass * 2 * nh);
     h->h_lin_b.assign(lb, lb + nclass);
+  }
+  if (h->h3 && h->cfg.lstm) {
+    for (int l = 0; l < 2; l++) {
+      h->h_wih_h3[l].resize(h->h_wih[l].size() * 2);
+      h->wih_us[l] = to_f16x3_host(h->h_wih[l].data(), h->h_wih[l].size(), h->h_wih_h3[l].data());
+    }
+    h->h_emb0_h3.resize(h->h_emb_w[0].size() * 2);
+    h->emb0_us = to_f16x3_host(h->h_emb_w[0].data(), h->h_emb_w[0].size(), h->h_emb0_h3.data());
   }
   if (h->cls_filter) {
     const std::vector<float>& wsrc = h->cfg.lstm ? h->h_emb_w[1] : h->h_lin_w;
@@ -1532,6 +1567,8 @@ void crnn_destroy(crnn_handle* h) {
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4h[i]);
+    for (int l = 0; l < 2; l++) (void)hipFree(h->d_wih_h3[l]);
+    (void)hipFree(h->d_emb0_h3);
     (void)hipFree(h->d_cls_wnorm);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }

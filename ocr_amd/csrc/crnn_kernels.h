@@ -29,6 +29,11 @@ struct ConvGemm {
   int nbatch;         // 0 or 1 = not batched
   long bsA, bsW, bsC;
   int gn;             // lin_gemm_kernel: column groups of the XCD split (set by launch_lin_gemm)
+  // f16x3 form (lin_gemm_h3_kernel; no arg-max): A and Wt hold (hi, lo) fp16 pairs (crnn_kernels.hip), rs[row / 128] = 1 / the
+  // scale of that block of rows (launch_rows_to_f16x3), us = 1 / the weights' scale (to_f16x3_host)
+  int h3;
+  const float* rs;
+  float us;
 };
 
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
@@ -192,6 +197,8 @@ void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s);
 // vs / us: unscale factors of f16x3 products (per tile, per layer) or nullptr / 1
 void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
                       int Cout, int act, int pool, hipStream_t s, const float* vs = nullptr, float us = 1.f);
+// fp32 rows [M][K] (K = 256 or 512; false for any other K) -> f16x3 rows + one unscale factor per block of 128 rows
+bool launch_rows_to_f16x3(const float* A, float* out, float* rs, int M, int K, hipStream_t s);
 // host: rows of K floats -> the f16x3 format with ONE scale for the whole tensor; returns 1 / scale
 float to_f16x3_host(const float* src, size_t n, uint16_t* dst /* 2 n halves */);
 

@@ -1817,6 +1817,203 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
   __builtin_amdgcn_s_waitcnt(0x0F70);     // no LDS write may be in flight when the block ends
 }
 
+// The same kernel on operands in the f16x3 format (A converted by rows_to_f16x3_kernel with one scale per 128-row block
+// = per unit, rs[m-tile] = 1 / scale; W converted at load time with one scale, us = 1 / scale):
+// C = act((hi hi + hi lo + lo hi) rs us + bias).
+__global__ __launch_bounds__(512, 1) void lin_gemm_h3_kernel(const ConvGemm p) {
+  constexpr int NWN = 4, NT = 512, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32, NLA = 2;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];   // [B0 B1 B2 | A0 A1 A2]
+  __shared__ float sbias[LIN_MAXN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int ntn = (p.N + TBN - 1) / TBN, ntm = (p.M + TBM - 1) / TBM;
+  const int NU = ntm * ntn, G = gridDim.x;
+  // Which units this block takes.  Small launches (G < 256): unit L + k G, L the XCD-aware block order.
+  // Full launches: the 8 XCDs split the unit grid into gn column groups x 8/gn row groups, and the G/8 blocks
+  // of an XCD stride through their rectangle row-major -- the rectangle's slice of W stays in that XCD's L2
+  // and an A tile is fetched once per column group instead of once per XCD and n-tile.
+  int nb, ne, gw, mb, me, first, stride, my_units;
+  if (p.gn > 0 && G == 256) {
+    const int x = blockIdx.x & 7, gm = 8 / p.gn, cg = x % p.gn, rg = x / p.gn;
+    nb = cg * ntn / p.gn; ne = (cg + 1) * ntn / p.gn;
+    mb = rg * ntm / gm; me = (rg + 1) * ntm / gm;
+    first = blockIdx.x >> 3; stride = G >> 3;
+  } else {
+    const int chunk = G >> 3;
+    nb = 0; ne = ntn; mb = 0; me = ntm;
+    first = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3); stride = G;
+  }
+  gw = ne - nb;
+  const int NUx = gw * (me - mb);
+  if (first >= NUx) return;
+  my_units = (NUx - first + stride - 1) / stride;
+  (void)NU;
+  for (int i = tid; i < ntn * TBN; i += NT) sbias[i] = i < p.N ? p.bias[i] : 0.f;
+  __syncthreads();
+
+  // loader: local row and k-chunk byte offset of this lane's LDS chunk positions
+  int lrow[2];
+  unsigned lkb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+    lrow[i] = 2 * S + (c16 >> 3);
+    lkb[i] = (unsigned)((c16 & 7) * 16);
+  }
+  unsigned aoff[2], boff[2];
+  auto offsets = [&](int q) __attribute__((always_inline)) {
+    const int qm = q / gw, mt = mb + qm, nt = nb + q - qm * gw;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      int m = mt * TBM + lrow[i], n = nt * TBN + lrow[i];
+      m = m < p.M ? m : p.M - 1;
+      n = n < p.N ? n : p.N - 1;
+      aoff[i] = (unsigned)m * (unsigned)(p.K * 4) + lkb[i];
+      boff[i] = (unsigned)n * (unsigned)(p.K * 4) + lkb[i];
+    }
+  };
+  const int nk = p.K / BK;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;
+  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+    unsigned m0_saved;   // M0 is restored: the compiler may keep a value of its own there (clobbering it is not allowed)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  };
+  const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.Wt;
+  int l_u = first, l_k0 = 0;
+  offsets(l_u);
+  auto gload = [&](int stage) __attribute__((always_inline)) {
+    const i32x4 a_rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa),
+                          __builtin_amdgcn_readfirstlane((int)((pa >> 32) & 0xFFFF)), 0x7FFFFFFF, 0x00020000};
+    const i32x4 b_rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)pb),
+                          __builtin_amdgcn_readfirstlane((int)((pb >> 32) & 0xFFFF)), 0x7FFFFFFF, 0x00020000};
+    const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
+    const int soff = __builtin_amdgcn_readfirstlane(l_k0 * 4);
+#pragma unroll
+    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], soff);
+#pragma unroll
+    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * NT * 16, boff[i], soff);
+    l_k0 += BK;
+    if (l_k0 == p.K) {   // next unit of this block (past the last one: re-read it into a stage nobody reads)
+      l_k0 = 0;
+      if (l_u + stride < NUx) l_u += stride;
+      offsets(l_u);
+    }
+  };
+
+  int ahi[2], alo[2], bhi[2], blo[2];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = 4 * j + 2 * h;
+      ahi[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | c) ^ ((Ra >> 1) & 15)) << 2);
+      alo[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (c + 1)) ^ ((Ra >> 1) & 15)) << 2);
+      bhi[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | c) ^ ((Rb >> 1) & 15)) << 2);
+      blo[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (c + 1)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+  int kc = 0, c_u = first;
+  const int act = p.act, half = lane >> 5;
+  // The MFMAs take the weight fragment as their first operand, so the product sits transposed in the
+  // accumulators: lane & 31 = row (m) of the 32-row sub-tile, register r = column 8 (r >> 2) + 4 half + (r & 3).
+  // A lane then owns four consecutive columns of one row per register quad (16-byte stores), and the row's
+  // arg-max over the wave's 32 columns is an in-lane scan plus one exchange between the half-waves.
+  const float us = p.us;
+  auto flush = [&]() __attribute__((always_inline)) {
+    const int qm = c_u / gw, mt = mb + qm, nt = nb + c_u - qm * gw;
+    const int col0 = nt * TBN + wn * 32 + 4 * half;
+    const float r = p.rs[mt] * us;     // one scale per 128-row block = per unit: a scalar load (not in vmcnt)
+#pragma unroll
+    for (int m2 = 0; m2 < 2; m2++) {
+      const int row = mt * TBM + wm * 64 + m2 * 32 + (lane & 31);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int col = col0 + 8 * g;
+        const f32x4 bias = *(const f32x4*)(sbias + col);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v[e] = acc[m2][4 * g + e] * r + bias[e];
+          acc[m2][4 * g + e] = 0.f;
+          const float neg = act == 2 ? 0.2f * v[e] : (act == 1 ? 0.f : v[e]);
+          v[e] = v[e] > 0.f ? v[e] : neg;
+        }
+        if (row < p.M) {
+          float* dst = p.C + (long)row * p.ldc + col;
+          if (col + 3 < p.N) *(f32x4u*)dst = v;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              if (col + e < p.N) dst[e] = v[e];
+          }
+        }
+      }
+    }
+    kc = 0;
+    c_u += stride;
+  };
+
+  f16x8 a0h[2], a0l[2], a1h[2], a1l[2], bh[2], bl[2];
+  auto frag = [&](int stage, int j, int set) __attribute__((always_inline)) {
+    const float* sa = smem + 3 * SB + stage * SA;
+    const float* sb = smem + stage * SB;
+    a0h[set] = *(const f16x8*)(sa + ahi[j]);
+    a0l[set] = *(const f16x8*)(sa + alo[j]);
+    a1h[set] = *(const f16x8*)(sa + ahi[j] + 1024);
+    a1l[set] = *(const f16x8*)(sa + alo[j] + 1024);
+    bh[set] = *(const f16x8*)(sb + bhi[j]);
+    bl[set] = *(const f16x8*)(sb + blo[j]);
+  };
+  auto mfma6 = [&](int set) __attribute__((always_inline)) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[set], a0h[set], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[set], a1h[set], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a0l[set], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a1l[set], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a0h[set], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a1h[set], acc[1], 0, 0, 0);
+  };
+  auto step = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
+    frag(st, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // see wino4_gemm_kernel
+    __syncthreads();
+    gload(st);
+    frag(nx, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kc == nk) flush();
+  };
+
+  const int nit = my_units * nk;
+  gload(0);
+  gload(1);
+  gload(2);
+  constexpr int LPS = NLA + 2;
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));
+  __syncthreads();
+  frag(0, 0, 0);
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // no LDS write may be in flight when the block ends
+}
+
 bool lin_gemm_ok(const ConvGemm& p) {
   // plain GEMM, K a multiple of 32, byte offsets below 2 GiB, bias of all n-tiles fits in LDS
   const long ntn = (p.N + 127) / 128;
@@ -1839,7 +2036,8 @@ void launch_lin_gemm(const ConvGemm& p0, hipStream_t s) {
     }
     if (force >= 0) p.gn = force;
   }
-  if (p.pmax) hipLaunchKernelGGL((lin_gemm_kernel<true>), dim3(g), dim3(512), 0, s, p);
+  if (p.h3) hipLaunchKernelGGL(lin_gemm_h3_kernel, dim3(g), dim3(512), 0, s, p);   // no arg-max form (checked by the caller)
+  else if (p.pmax) hipLaunchKernelGGL((lin_gemm_kernel<true>), dim3(g), dim3(512), 0, s, p);
   else hipLaunchKernelGGL((lin_gemm_kernel<false>), dim3(g), dim3(512), 0, s, p);
 }
 
@@ -2301,6 +2499,15 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(const float* __restrict__
     __syncthreads();
     cur ^= 1;
   }
+  // padding rows (t >= T_i) of this workgroup's lines and direction: zero, so that what follows (the f16x3 conversion takes
+  // the maximum over blocks of 128 rows) never sees stale workspace contents
+  for (int ln = 0; ln < LB; ln++) {
+    const int bb = b0 + ln;
+    if (bb >= B) break;
+    const int Tl = tlen ? tlen[bb] : T;
+    for (int r = Tl * 64 + tid; r < T * 64; r += 256)
+      *(f32x4*)(rec + ((size_t)bb * T + (r >> 6)) * 512 + dir * 256 + (r & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2570,6 +2777,56 @@ void launch_argmax_partials(const float* pmax, const int32_t* pidx, int32_t* idx
 // candidates (usually one, then nothing is left to do) are scored exactly: fp32 dot products of the fp32
 // activations and weights, ties to the lowest index.  The decision is therefore made in fp32; bf16 only prunes.
 // ---------------------------------------------------------------------------
+// fp32 rows [M][K] -> the f16x3 format with one scale per block of 128 rows (rs[block] = 1 / scale): the block is a
+// GEMM unit's rows, so the GEMM's epilogue needs one scalar per unit.  One 1024-thread workgroup per block; a thread
+// owns 8 consecutive channels of 128 * K / 8192 rows (all held in registers between the maximum and the conversion).
+template <int K>
+__global__ __launch_bounds__(1024) void rows_to_f16x3_kernel(const float* __restrict__ A, float* __restrict__ out,
+                                                             float* __restrict__ rs, int M) {
+  constexpr int TPR = K / 8, RPI = 1024 / TPR, NIT = 128 / RPI;
+  __shared__ float wmax[16];
+  const int r0 = blockIdx.x * 128 + threadIdx.x / TPR, g8 = threadIdx.x % TPR;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 v[NIT][2];
+  float mx = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int row = r0 + it * RPI;
+    const float* a = A + (long)(row < M ? row : 0) * K + g8 * 8;
+    v[it][0] = row < M ? *(const f32x4*)a : z;
+    v[it][1] = row < M ? *(const f32x4*)(a + 4) : z;
+#pragma unroll
+    for (int e = 0; e < 4; e++) mx = fmaxf(mx, fmaxf(__builtin_fabsf(v[it][0][e]), __builtin_fabsf(v[it][1][e])));
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 16; w++) mx = fmaxf(mx, wmax[w]);
+  float sc, uns;
+  split_scale_from_max(mx, sc, uns);
+  if (threadIdx.x == 0) rs[blockIdx.x] = uns;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int row = r0 + it * RPI;
+    if (row >= M) continue;
+    uint2 h0, l0, h1, l1;
+    split4(v[it][0], sc, h0, l0);
+    split4(v[it][1], sc, h1, l1);
+    uint4* o = (uint4*)(out + (long)row * K + g8 * 8);
+    o[0] = uint4{h0.x, h0.y, h1.x, h1.y};
+    o[1] = uint4{l0.x, l0.y, l1.x, l1.y};
+  }
+}
+bool launch_rows_to_f16x3(const float* A, float* out, float* rs, int M, int K, hipStream_t s) {
+  const dim3 g((M + 127) / 128);
+  if (K == 512) hipLaunchKernelGGL((rows_to_f16x3_kernel<512>), g, dim3(1024), 0, s, A, out, rs, M);
+  else if (K == 256) hipLaunchKernelGGL((rows_to_f16x3_kernel<256>), g, dim3(1024), 0, s, A, out, rs, M);
+  else return false;
+  return true;
+}
+
 __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ A, uint16_t* __restrict__ out,
                                                            float* __restrict__ norm, int M, int K) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
