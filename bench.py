@@ -14,6 +14,17 @@ snapshot); timing does not depend on weight values.
 One process per GPU, every rank runs its own replica on its own lines (weak scaling,
 no data-path collective; gloo is used only for the barrier and the max over ranks).
 Rank 0 prints ONE JSON line.
+
+  python bench.py --lines 1000000 [--gpus N] [--precision fp32|bf16]
+BASELINE.json configs[3]: a fixed job of N synthetic 32x280 lines, generated on each GPU from a seed
+before the timed region (resident in HBM), cut into width buckets and dealt to the ranks by
+ocr_amd/crnn/parallel.py (strong scaling: the job is fixed, the ranks share it); the timed region runs every
+rank's buckets through the pipeline and gathers the decoded strings of all ranks on the host.
+
+What the timed region of the default mode contains and what it does not: it starts from uint8 lines of height
+32 already in HBM (no upload, no resize -- those are tools/bench_configs.py's crop-replay figures, the
+like-for-like number beside the CPU baseline, which starts from host images) and ends with Python strings on
+the host (labels copied back per batch, vectorised code-point lookup).
 """
 import argparse
 import gc
@@ -24,8 +35,10 @@ import time
 
 import numpy as np
 
-# the lanes are HIP streams: give the runtime enough hardware queues for them (before HIP initialises;
-# see ocr_amd/crnn/_capi.py _more_hw_queues)
+# The lanes are HIP streams: the runtime needs enough hardware queues for them (GPU_MAX_HW_QUEUES, read when HIP
+# initialises; its default of 4 makes four lanes slower than three).  A deployment exports the variable itself
+# (INTEGRATION.md); this script sets it when it is unset, before anything initialises HIP, and the value in effect is
+# recorded in the JSON line (config.gpu_max_hw_queues).  See ocr_amd/crnn/_capi.py _more_hw_queues.
 if not os.environ.get("CRNN_KEEP_HW_QUEUES") and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
@@ -35,8 +48,10 @@ sys.path.insert(0, ROOT)
 BATCH, WIDTH, NCLASS = 256, 280, 5530
 FLOP_PER_LINE = 4283.46e6          # 2*MACs per 32x280 line, nclass 5530
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32 MFMA peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+# direct-form FLOPs (2 * MACs) per 32x280 line of the conv layers
+DIRECT_MFLOP = {"conv1": 330.30, "conv2": 330.30, "conv3": 660.60, "conv4": 670.04, "conv5": 1340.08, "conv6": 148.90}
 
 
 def cpu_baseline(lines_u8, sd, alphabet, want_seconds=12.0):
@@ -77,12 +92,119 @@ def char_agreement(got, want):
     return 1.0 - err / max(1, tot)
 
 
+def lines_job(args, model, dev, rank, world, dist):
+    """BASELINE configs[3]: a fixed job of args.lines synthetic 32x280 lines.  Every rank computes the same partition
+    (ocr_amd/crnn/parallel.py: width buckets dealt to ranks by cost), generates ITS lines on its GPU from the seed
+    (bucket j of the job always holds the same lines, whatever the number of ranks), and -- timed -- runs its buckets
+    through the lane pipeline, turns the labels into strings and gathers the strings of all ranks on the host."""
+    import torch
+    from ocr_amd.crnn.parallel import my_buckets
+    N = args.lines
+    NL = model.lanes
+    T = WIDTH // 4 + 1
+    widths = [WIDTH] * N
+    mine = my_buckets(widths, rank, world, max_batch=BATCH)          # list of index lists (<= 256 lines each)
+    nmine = sum(len(b) for b in mine)
+    # the rank's lines, resident in HBM before the timed region; bucket j's lines come from seed + first index of j
+    d_lines = torch.empty((max(nmine, 1), 32, WIDTH), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    offs, o = [], 0
+    for b in mine:
+        gen.manual_seed(args.seed * 1000003 + b[0])
+        d_lines[o:o + len(b)] = torch.randint(0, 256, (len(b), 32, WIDTH), dtype=torch.uint8, device=dev, generator=gen)
+        offs.append(o)
+        o += len(b)
+    NS = NL + 1
+    d_lab = [torch.zeros((BATCH, T), dtype=torch.int32, device=dev) for _ in range(NS)]
+    d_len = [torch.zeros((BATCH,), dtype=torch.int32, device=dev) for _ in range(NS)]
+    h_lab = [torch.zeros((BATCH, T), dtype=torch.int32).pin_memory() for _ in range(NS)]
+    h_len = [torch.zeros((BATCH,), dtype=torch.int32).pin_memory() for _ in range(NS)]
+    ext = [torch.cuda.ExternalStream(model.stream_ptr(l), device=dev) for l in range(NL)]
+    evs = [torch.cuda.Event() for _ in range(NS)]
+    torch.cuda.synchronize()
+
+    def launch(k):
+        s, n = k % NS, len(mine[k])
+        lane = model.forward_device(d_lines[offs[k]].data_ptr(), n, WIDTH, d_lab[s].data_ptr(), d_len[s].data_ptr())
+        with torch.cuda.stream(ext[lane]):
+            h_lab[s].copy_(d_lab[s], non_blocking=True)
+            h_len[s].copy_(d_len[s], non_blocking=True)
+            evs[s].record(ext[lane])
+
+    def collect(k, part):
+        s, n = k % NS, len(mine[k])
+        evs[s].synchronize()
+        for i, t in zip(mine[k], model.texts_from_labels(h_lab[s].numpy()[:n], h_len[s].numpy()[:n])):
+            part[i] = t
+
+    def job(buckets):
+        part = {}
+        for k in buckets:
+            launch(k)
+            if k - buckets[0] >= NL:
+                collect(k - NL, part)
+        for k in buckets[max(0, len(buckets) - NL):]:
+            collect(k, part)
+        return part
+
+    nb = len(mine)
+    job(list(range(min(nb, max(args.warmup, NL)))))       # warm-up: workspace allocation, clocks
+    model.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    part = job(list(range(nb)))
+    model.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, part)                # the host gather of decoded strings (no device collective)
+        dist.barrier()
+    else:
+        parts = [part]
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    total = sum(len(p) for p in parts)
+    assert total == N, (total, N)
+    if rank == 0:
+        chars = sum(len(t) for p in parts for t in p.values())
+        steps = max(1, (N + BATCH - 1) // BATCH)
+        out = {"metric": "text-lines/sec at 32x280 crops (CRNN ocr-lstm head, 5530 classes)",
+               "value": round(N / elapsed, 1), "unit": "text-lines/s", "n_gpus": world, "steps": steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
+               "data": "synthetic (uniform uint8 lines generated on-device from a seed, seeded synthetic weights)",
+               "config": {"workload": "configs[3]: %d synthetic 32x280 lines, generated on-device from seed %d, width-bucketed "
+                                      "(256 lines) and sharded over %d GPU(s) by rank, CRNN %s; decoded strings gathered on "
+                                      "the host (timed)" % (N, args.seed, world, args.precision),
+                          "lines": N, "batch": BATCH, "width": WIDTH, "nclass": NCLASS, "lanes_per_gpu": NL,
+                          "buckets_rank0": nb, "sharding": "independent lines, one replica per GPU, no collective",
+                          "gpu_max_hw_queues": _hw_queues()},
+               "elapsed_s": round(elapsed, 3), "decoded_chars": chars}
+        print(json.dumps(out, ensure_ascii=False))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _hw_queues():
+    from ocr_amd.crnn import _capi
+    return _capi.effective_hw_queues()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--lanes", type=int, default=4, help="independent stream/workspace lanes per GPU")
+    ap.add_argument("--lines", type=int, default=0,
+                    help="BASELINE configs[3]: a fixed job of this many synthetic 32x280 lines (1000000 in the config), "
+                         "generated on-device from --seed and sharded over the ranks; 0 = the default per-step mode")
+    ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="fp32 = the headline, parity-exact path; bf16 = bf16 MFMA inputs, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,6 +286,9 @@ def main():
             return texts
         return run, d_lab, d_len
 
+    if args.lines > 0:
+        return lines_job(args, model, dev, rank, world, dist)
+
     run, d_lab, d_len = pipeline(model)
 
     def barrier():
@@ -199,36 +324,71 @@ def main():
                 acc[name] = [0.0, fl, by]
                 order.append(name)
             acc[name][0] += ms / nprof
+    # the preprocessing kernels of the host-image path (gray conversion + Pillow-exact resize + normalise): 256 BGR crops of
+    # 64x560 in one bucket through predict_lines, per-kernel device times of that call (HBM stages of the north star)
+    pre_stages = []
+    if world == 1 and not args.serial:
+        crops = [rs.randint(0, 256, size=(64, 560, 3)).astype(np.uint8) for _ in range(BATCH)]
+        model.predict_lines(crops[:8], max_batch=BATCH)
+        model.predict_lines(crops, max_batch=BATCH)
+        for name, ms, fl, by in model.kernel_times():
+            if name.startswith("resize"):
+                pre_stages.append({"stage": name + " (256 BGR crops 64x560 -> 32x280)", "ms": round(ms, 4),
+                                   "gbs": round(by / (ms * 1e-3) / 1e9, 1),
+                                   "frac_of_hbm_peak": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
     model.set_profiling(False)
+    # like-for-like with the CPU baseline: the SAME 256 host lines the CPU baseline gets, from host memory to Python strings
+    # through CRNN.predict_lines (upload, resize path, network, copy-back, decode), several batches kept in flight by threads
+    host_path = None
+    if world == 1 and not args.serial and not args.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
+        hl = list(host_lines[0])
+        model.predict_lines(hl, max_batch=BATCH)
+        reps = 12
+        with ThreadPoolExecutor(min(NL, 4)) as ex:
+            th = time.perf_counter()
+            res = list(ex.map(lambda _: model.predict_lines(hl, max_batch=BATCH), range(reps)))
+            eh = time.perf_counter() - th
+        host_path = {"value": round(BATCH * reps / eh, 1), "unit": "text-lines/s",
+                     "what": "CRNN.predict_lines on the CPU baseline's own 256 host lines (host uint8 arrays in, strings out; "
+                             "%d calls from %d threads)" % (reps, min(NL, 4)),
+                     "strings_identical_to_headline_path": "%d/%d" % (sum(a == b for a, b in zip(first_texts, res[-1])), BATCH)}
 
-    # ---- the same pipeline with the classifier's arg-max taken from a plain fp32 GEMM (no bf16 pre-filter), for
-    # reference beside the headline (rank 0 of a one-GPU run only; outside the timed region above)
+    # ---- the same pipeline with parts of the arithmetic switched back to the f32 MFMA, for reference beside the headline
+    # (rank 0 of a one-GPU run only; outside the timed region above): the classifier's arg-max from a plain fp32 GEMM (no
+    # bf16 pre-filter), the Winograd / projection GEMMs on the f32 MFMA (no f16x3), and both
     plain = None
-    if (args.precision == "fp32" and world == 1 and not args.serial
-            and os.environ.get("CRNN_CLS_FILTER", "1") != "0" and not args.no_cpu_baseline):
+    if (args.precision == "fp32" and world == 1 and not args.serial and not args.no_cpu_baseline
+            and os.environ.get("CRNN_CLS_FILTER", "1") != "0" and os.environ.get("CRNN_F16X3", "1") != "0"):
         # pinned result buffers remember the lane streams they were used on: free them (the closure) before the handle
         run = None
         gc.collect()
         model.__del__()          # frees the first handle's streams: both handles' lanes would share the hardware queues
-        os.environ["CRNN_CLS_FILTER"] = "0"
-        model2 = CRNN(32, 1, NCLASS, 256, leakyRelu=False, lstmFlag=True, GPU=True, alphabet=keys.alphabetChinese,
-                      device=local_rank, lanes=args.lanes, precision=args.precision)
-        del os.environ["CRNN_CLS_FILTER"]
-        model2.load_state_dict(sd)
-        run2, _, _ = pipeline(model2)
-        texts2 = run2(1)
-        run2(args.warmup)
-        model2.synchronize()
-        t2 = time.perf_counter()
-        run2(args.steps)
-        model2.synchronize()
-        e2 = time.perf_counter() - t2
-        plain = {"value": round(BATCH * args.steps / e2, 1), "unit": "text-lines/s",
-                 "ms_per_step": round(e2 / args.steps * 1e3, 3),
-                 "strings_identical_to_headline_path": "%d/%d" % (sum(a == b for a, b in zip(first_texts, texts2)), len(texts2))}
-        run2 = None
-        gc.collect()
-        del model2
+        plain = {}
+        for tag, env in (("classifier_plain_fp32_gemm", {"CRNN_CLS_FILTER": "0"}),
+                         ("gemms_on_f32_mfma", {"CRNN_F16X3": "0"}),
+                         ("all_on_f32_mfma", {"CRNN_CLS_FILTER": "0", "CRNN_F16X3": "0"})):
+            os.environ.update(env)
+            model2 = CRNN(32, 1, NCLASS, 256, leakyRelu=False, lstmFlag=True, GPU=True, alphabet=keys.alphabetChinese,
+                          device=local_rank, lanes=args.lanes, precision=args.precision)
+            for k in env:
+                del os.environ[k]
+            model2.load_state_dict(sd)
+            run2, _, _ = pipeline(model2)
+            texts2 = run2(1)
+            run2(args.warmup)
+            model2.synchronize()
+            t2 = time.perf_counter()
+            run2(args.steps)
+            model2.synchronize()
+            e2 = time.perf_counter() - t2
+            plain[tag] = {"value": round(BATCH * args.steps / e2, 1), "unit": "text-lines/s",
+                          "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                          "strings_identical_to_headline_path": "%d/%d" % (sum(a == b for a, b in zip(first_texts, texts2)), len(texts2))}
+            run2 = None
+            gc.collect()
+            model2.__del__()
+            del model2
 
     run = None          # same order at every exit: pinned buffers (held by the closure) go before the handle's streams
     gc.collect()
@@ -237,105 +397,159 @@ def main():
             dist.destroy_process_group()
         return
 
-    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    fp32 = args.precision == "fp32"
+    h3 = fp32 and os.environ.get("CRNN_F16X3", "1") != "0"         # Winograd / projection GEMMs on the fp16 MFMA (f16x3)
     lines_total = BATCH * args.steps * world
     value = lines_total / elapsed
-    gemm_names = [n for n in order if (n.startswith("conv") and n != "conv0_pool0" and "_win" not in n and "_wout" not in n)
-                  or n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
-    # GEMM kernels of the fp32 path: conv2-5 run as Winograd F(4x4) and conv6 as 1-D F(4,2) ("<layer>_f4":
-    # wino4_gemm_lw_kernel), conv1 as fused F(2x2) (a "<layer>_win" launch before it: wino_gemm_dma_kernel), the LSTM input projections and the
-    # classifier on lin_gemm_kernel (same persistent direct-to-LDS pipeline as wino4_gemm_kernel), conv6 and the
-    # embedding on conv_gemm_kernel.  The roofline object is for whichever kernel takes most of the step
-    # (rocprof's per-kernel average is over the same launches).
-    wino_names = [n for n in gemm_names if (n.split("_")[0] + "_win") in order]
-    wino4_names = [n for n in gemm_names if n.endswith("_f4")]
-    lin_on = args.precision == "fp32" and os.environ.get("CRNN_LIN_GEMM", "1") != "0"
-    lin_names = [n for n in gemm_names if lin_on and n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
-    direct_names = [n for n in gemm_names if n not in wino_names + wino4_names + lin_names]
-    direct_kernel = "conv_gemm_kernel" if args.precision == "fp32" else "conv_gemm_bf16_kernel"
+    step_s = elapsed / args.steps
+    # ---- GEMM kernel families.  acc[name] = [ms per launch (HIP events on the library's stream, batches run one at a
+    # time), fp32 FLOPs of the launch as executed (2 M N K of the GEMMs the kernel really runs: Winograd component
+    # GEMMs, not the direct form), algorithmic bytes].  An f16x3 kernel executes THREE fp16 MFMA products per fp32
+    # product: its roofline is the fp16 MFMA's, with 3x those FLOPs.
+    wino4_names = [n for n in order if n.endswith("_f4")]
+    lin_on = fp32 and os.environ.get("CRNN_LIN_GEMM", "1") != "0"
+    lin_names = [n for n in order if lin_on and n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
+    other_names = [n for n in order if (n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier") or
+                                        (n.startswith("conv") and n != "conv0_pool0" and "_win" not in n and "_wout" not in n))
+                   and n not in wino4_names + lin_names]
 
-    def family(kernel, names, what):
+    def family(kernel, names, what, products, peak):
         ms = sum(acc[n][0] for n in names)
         fl = sum(acc[n][1] for n in names)
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {"kernel": "%s (%s; %d launches per step)" % (kernel, what, len(names)), "launches": names,
-                "ms_per_step": round(ms, 4), "achieved": round(ach, 2), "frac": round(ach / peak, 4),
-                "flops_per_launch_avg": fl / max(1, len(names)),
-                "algorithmic_bytes_per_launch_avg": sum(acc[n][2] for n in names) / max(1, len(names)),
-                "ms_per_launch_avg": round(ms / max(1, len(names)), 4)}
+        eq = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0        # fp32 GEMM FLOPs per second
+        direct = sum(DIRECT_MFLOP.get(n.split("_")[0], 0.0) for n in names) * 1e6 * BATCH
+        f = {"kernel": "%s (%s; %d launches per step)" % (kernel, what, len(names)), "launches": names,
+             "ms_per_step": round(ms, 4), "ms_per_launch_avg": round(ms / max(1, len(names)), 4),
+             "achieved": round(eq * products, 2), "peak": peak, "frac": round(eq * products / peak, 4),
+             "mfma_products_per_fp32_product": products,
+             "fp32_equivalent_tflops": round(eq, 2),
+             "fp32_equivalent_over_f32_mfma_peak": round(eq / PEAK_F32_MFMA_TFLOPS, 4),
+             "flops_per_launch_avg": products * fl / max(1, len(names)),
+             "algorithmic_bytes_per_launch_avg": sum(acc[n][2] for n in names) / max(1, len(names))}
+        if direct:
+            f["direct_form_tflops"] = round(direct / (ms * 1e-3) / 1e12, 2)
+            f["direct_form_over_f32_mfma_peak"] = round(direct / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+        return f
     fams = []
-    if wino_names:
-        fams.append(family("wino_gemm_dma_kernel", wino_names,
-                           "Winograd F(2x2,3x3) GEMM + output transform, executed MFMA FLOPs; a launch here is one layer = "
-                           "the 128x128-tile launch over the full rounds plus the small-tile launch over the remaining tiles"))
     if wino4_names:
-        fams.append(family("wino4_gemm_lw_kernel", wino4_names,
-                           "Winograd component GEMMs of a layer -- 36 for F(4x4,3x3) on conv2-5, 5 for conv6's 1-D F(4,2) -- "
-                           "as one persistent launch of 128x128 units, executed MFMA FLOPs"))
+        if h3:
+            fams.append(family("wino4_gemm_h3_kernel", wino4_names,
+                               "Winograd component GEMMs of a layer -- 36 for F(4x4,3x3) on conv1-5, 5 for conv6's 1-D F(4,2) -- as one "
+                               "persistent launch of 128x128 units on the fp16 MFMA, operands as (hi, lo) fp16 pairs, 3 MFMA products per "
+                               "fp32 product", 3, PEAK_BF16_MFMA_TFLOPS))
+        else:
+            fams.append(family("wino4_gemm_lw_kernel", wino4_names,
+                               "Winograd component GEMMs of a layer as one persistent launch of 128x128 units on the f32 MFMA", 1,
+                               PEAK_F32_MFMA_TFLOPS))
     if lin_names:
-        fams.append(family("lin_gemm_kernel", lin_names, "plain GEMMs as persistent launches of 128x128 units: " +
-                           ", ".join(lin_names)))
-    if direct_names:
-        fams.append(family(direct_kernel, direct_names, "implicit GEMM: " + ", ".join(direct_names)))
+        h3l = [n for n in lin_names if h3 and n != "classifier"]
+        if h3l:
+            fams.append(family("lin_gemm_h3_kernel", h3l, "plain GEMMs (" + ", ".join(h3l) + ") as persistent launches of 128x128 "
+                               "units on the fp16 MFMA, f16x3 operands", 3, PEAK_BF16_MFMA_TFLOPS))
+        f32l = [n for n in lin_names if n not in h3l]
+        if f32l:
+            fams.append(family("lin_gemm_kernel", f32l, "plain GEMMs on the f32 MFMA: " + ", ".join(f32l), 1, PEAK_F32_MFMA_TFLOPS))
+    if other_names:
+        fams.append(family("conv_gemm_kernel" if fp32 else "conv_gemm_bf16_kernel", other_names,
+                           "implicit GEMM: " + ", ".join(other_names), 1, PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS))
     fams.sort(key=lambda f: -f["ms_per_step"])
     dom = fams[0]
     gemm_names = dom["launches"]
     kernels = {n: {"ms": round(acc[n][0], 4),
                    "tflops": round(acc[n][1] / (acc[n][0] * 1e-3) / 1e12, 2) if acc[n][1] else None,
                    "gbs_algorithmic": round(acc[n][2] / (acc[n][0] * 1e-3) / 1e9, 1)} for n in order}
-    # HBM traffic of the same launches from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in separate runs, gfx950 x2 read correction; tools/pmc_traffic.py).  PMC counters
-    # cannot be collected from inside this process, so the figure comes from profiles/.
+    # HBM traffic of the same launches from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # runs, gfx950 x2 read correction; tools/pmc_traffic.py).  PMC counters cannot be collected from inside this process,
+    # so the figure comes from profiles/ and the line says which file and which commit of it.
     traffic, traffic_src = None, None
-    tp = os.path.join(ROOT, "profiles", "r1_pmc_traffic_%s.json" % args.precision)
-    if os.path.exists(tp):
+    for rnd in ("r2", "r1"):
+        tp = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, args.precision))
+        if not os.path.exists(tp):
+            continue
         with open(tp) as f:
             tj = json.load(f)
-        if all(n in tj for n in gemm_names):
-            # a Winograd layer is two launches (full rounds + "<layer>_tail"): count both
-            traffic = sum(tj[n]["hbm_bytes"] + tj.get(n + "_tail", {}).get("hbm_bytes", 0.0) for n in gemm_names) / len(gemm_names)
+        if all(n in tj for n in gemm_names) and (not h3 or "wino4_gemm_h3" in tj[gemm_names[0]].get("kernel", "")):
+            traffic = sum(tj[n]["hbm_bytes"] for n in gemm_names) / len(gemm_names)
             traffic_src = "profiles/" + os.path.basename(tp)
+            try:
+                import subprocess
+                c = subprocess.run(["git", "log", "-1", "--format=%h", "--", tp], cwd=ROOT, capture_output=True, text=True, timeout=10)
+                if c.stdout.strip():
+                    traffic_src += " @ " + c.stdout.strip()
+            except Exception:  # noqa: BLE001
+                pass
+            break
+    # HBM-bound stages: achieved algorithmic GB/s and the fraction of the 8 TB/s peak (north star: preprocess, arg-max, decode)
+    hbm_names = [n for n in order if (acc[n][1] == 0 and n != "cls_filter_bf16") or n == "conv0_pool0"]
+    hbm_stages = [{"stage": n, "ms": round(acc[n][0], 4), "gbs": round(acc[n][2] / (acc[n][0] * 1e-3) / 1e9, 1),
+                   "frac_of_hbm_peak": round(acc[n][2] / (acc[n][0] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} for n in hbm_names]
+    # MFMA time at peak of every launch of a step / step time: how busy the matrix pipes are over the whole pipeline
+    cls_flops = 2.0 * BATCH * (WIDTH // 4 + 1) * NCLASS * 512
+    mfma_s = 0.0
+    for n in order:
+        if n == "cls_filter_bf16":
+            mfma_s += cls_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+        elif acc[n][1] and n != "conv0_pool0":
+            is_h3 = h3 and (n in wino4_names or n in ("lstm0_ih", "lstm1_ih", "emb0"))
+            mfma_s += (3.0 * acc[n][1] / (PEAK_BF16_MFMA_TFLOPS * 1e12)) if is_h3 else acc[n][1] / ((PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS) * 1e12)
+    serial_ms = sum(acc[n][0] for n in order)
+    peak = dom["peak"]
 
     out = {
         "metric": "text-lines/sec at 32x280 crops (CRNN ocr-lstm head, 5530 classes)",
         "value": round(value, 1), "unit": "text-lines/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "bf16",
+        "dtype": "f32" if fp32 else "bf16",
         "data": "synthetic (seeded uniform uint8 lines, seeded synthetic weights)",
         "config": {"workload": "configs[1]: CRNN %s, batch 256 synthetic 32x280 grayscale lines per step per GPU, "
                                "uint8 lines resident in HBM -> decoded strings on the host" % args.precision,
                    "batch": BATCH, "width": WIDTH, "nclass": NCLASS, "lines_per_step": BATCH * world,
-                   "lanes_per_gpu": NL,
+                   "lanes_per_gpu": NL, "gpu_max_hw_queues": _hw_queues(),
+                   "timed_region": "normalise -> conv stack -> 2x BiLSTM -> classifier arg-max -> CTC collapse on the GPU, label "
+                                   "copy-back and string assembly on the host; NOT in it: upload and resize of source images "
+                                   "(tools/bench_configs.py measures those: crop replay)",
                    "sharding": "independent lines, one replica per GPU, no collective"},
         "roofline": {
             "bound": "mfma", "kernel": dom["kernel"],
             "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s",
-            "frac": dom["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch (avg)",
+            "frac": dom["frac"],
+            "what_achieved_counts": ("MFMA FLOPs the kernel executes per second, measured alone on the device: %d MFMA product(s) per fp32 "
+                                     "product of the Winograd component GEMMs, against the dense peak of that MFMA type"
+                                     % dom["mfma_products_per_fp32_product"]),
+            "fp32_equivalent_tflops": dom["fp32_equivalent_tflops"],
+            "fp32_equivalent_over_f32_mfma_peak": dom["fp32_equivalent_over_f32_mfma_peak"],
+            "direct_form_tflops": dom.get("direct_form_tflops"),
+            "direct_form_over_f32_mfma_peak": dom.get("direct_form_over_f32_mfma_peak"),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (avg)",
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch_avg": dom["algorithmic_bytes_per_launch_avg"],
             "flops_per_launch_avg": dom["flops_per_launch_avg"],
             "ms_per_launch_avg": dom["ms_per_launch_avg"]},
         "roofline_other": [{k: v for k, v in f.items() if k != "launches"} for f in fams[1:]],
-        # direct-form algorithmic FLOPs (4.283 GFLOP per line) x lines/s.  The fp32 path runs
-        # conv1-5 as Winograd F(2x2,3x3) (2.25x fewer multiplies), so this "effective" rate can approach
-        # or pass the MFMA peak; roofline.achieved above counts the FLOPs the MFMAs actually execute.
+        "hbm_stages": pre_stages + hbm_stages,
+        # direct-form algorithmic FLOPs (4.283 GFLOP per line) x lines/s: an "effective" rate that Winograd, the
+        # classifier pre-filter and the f16x3 GEMMs push past the f32 MFMA peak; it is not a roofline figure
         "pipeline_tflops": round(FLOP_PER_LINE * value / 1e12, 2),
-        "pipeline_effective_frac_of_mfma_peak": round(FLOP_PER_LINE * value / 1e12 / (peak * world), 4),
-        # FLOPs the MFMAs execute per step (every GEMM launch + the recurrences) / step time: what the whole
-        # pipeline, lanes overlapped, sustains.  roofline.achieved is the dominant kernel measured ALONE on the
-        # device; with several lanes the library picks the 128x128 Winograd tile, which is slower alone at this
-        # batch (2.25 rounds of one block per CU) but faster in the pipeline, where other lanes fill its tail.
-        "pipeline_executed_mfma_tflops": round(sum(acc[n][1] for n in order if n != "conv0_pool0") * world
-                                               / (elapsed / args.steps) / 1e12, 2),
+        "pipeline_effective_frac_of_f32_mfma_peak": round(FLOP_PER_LINE * value / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+        # sum over a step's launches of (MFMA FLOPs executed / dense peak of that MFMA type) / step time
+        "pipeline_mfma_time_frac": round(mfma_s / step_s, 4),
+        "serial_kernel_ms_per_step": round(serial_ms, 4),
         "kernels": kernels,
     }
-    if args.precision == "fp32" and os.environ.get("CRNN_CLS_FILTER", "1") != "0":
+    if fp32 and os.environ.get("CRNN_CLS_FILTER", "1") != "0":
         out["config"]["classifier"] = ("arg-max decided in fp32: a bf16 GEMM with a rigorous error bound only prunes the "
                                        "5530 classes to the candidates (about 4 per row here), which are scored exactly in fp32 "
                                        "(DESIGN.md section 4; CRNN_CLS_FILTER=0 = plain fp32 GEMM)")
-        if plain:
-            out["classifier_plain_fp32_gemm"] = plain
+    if h3:
+        out["config"]["gemm_arithmetic"] = ("f16x3: every fp32 GEMM operand is carried as a (hi, lo) fp16 pair with a power-of-two "
+                                            "scale per row block, products hi*hi + hi*lo + lo*hi on the fp16 MFMA with fp32 "
+                                            "accumulation -- measured as accurate as the f32 MFMA against float64 "
+                                            "(tools/split_mfma_test.hip; DESIGN.md section 4); CRNN_F16X3=0 = f32 MFMA")
+    if plain:
+        out["alternatives_same_run"] = plain
+    if host_path:
+        out["gpu_host_path_same_inputs_as_cpu_baseline"] = host_path
     if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
         cb, cpu_texts = cpu_baseline(host_lines[0], sd, keys.alphabetChinese)
         out["cpu_baseline"] = cb

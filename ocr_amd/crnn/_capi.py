@@ -40,15 +40,35 @@ def _more_hw_queues():
     GPU_MAX_HW_QUEUES hardware queues (HIP's default, 4), and torch's own streams take some of those.
     With 4 lanes on 4 queues the step is SLOWER than with 3 (lanes sharing a queue serialise); with 8
     queues 4 lanes are worth +7 %.  Raises the setting to 8 when it is unset or lower (never lowers it);
-    CRNN_KEEP_HW_QUEUES=1 leaves it alone.  Only effective before the HIP runtime initialises."""
-    if os.environ.get("CRNN_KEEP_HW_QUEUES"):
-        return
+    CRNN_KEEP_HW_QUEUES=1 leaves it alone.  Only effective before the HIP runtime initialises: if torch
+    has already brought HIP up in this process the variable is left as it is and the number of queues
+    the runtime really has goes into CRNN_EFFECTIVE_HW_QUEUES, which makes crnn_create keep a handle at
+    three lanes (the fastest choice on four queues).  Deployments should export GPU_MAX_HW_QUEUES=8
+    themselves; this is the fallback for callers that did not."""
     try:
-        cur = int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))
+        cur = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
     except ValueError:
         cur = 0
-    if cur < 8:
+    if os.environ.get("CRNN_KEEP_HW_QUEUES") or cur >= 8:
+        return
+    import sys
+    torch = sys.modules.get("torch")
+    try:
+        hip_up = bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:  # noqa: BLE001
+        hip_up = False
+    if hip_up:
+        os.environ.setdefault("CRNN_EFFECTIVE_HW_QUEUES", str(cur or 4))
+    else:
         os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
+
+def effective_hw_queues():
+    """Hardware queues the HIP runtime of this process has (as far as this module can tell)."""
+    try:
+        return int(os.environ.get("CRNN_EFFECTIVE_HW_QUEUES") or os.environ.get("GPU_MAX_HW_QUEUES") or 4)
+    except ValueError:
+        return 4
 
 
 _more_hw_queues()   # at import: the earlier the better (must precede HIP initialisation)

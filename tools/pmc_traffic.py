@@ -32,6 +32,8 @@ ORDER_F4 += ["conv6_win4", "conv6_f4", "conv6_wout4",   # conv6 as 1-D F(4,2)
               "cls_to_bf16", "cls_filter_bf16", "cls_select", "ctc"]   # classifier: certified bf16 pre-filter
 MODE = sys.argv[4] if len(sys.argv) > 4 else "direct"
 ORDER = {"wino": ORDER_WINO, "fused": ORDER_FUSED, "hybrid": ORDER_HYBRID, "f4": ORDER_F4}.get(MODE, ORDER_DIRECT)
+if MODE.endswith(".json"):     # the launch order of a step as a bench.py line of the same build recorded it ("kernels")
+    ORDER = list(json.loads(open(MODE).read().strip().splitlines()[-1])["kernels"].keys())
 
 
 def per_launch(d, counter):
