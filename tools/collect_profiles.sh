@@ -1,0 +1,14 @@
+# copies what tools/profile_run.sh left under gpurun_out/<round>/ into profiles/ (tracked): tools/collect_profiles.sh r2
+R=${1:-r2}; O=gpurun_out/$R; P=profiles
+cp $O/final_fp32.json $P/${R}_bench_fp32.json
+cp $O/final_fp32_steps20.json $P/${R}_bench_fp32_steps20.json
+cp $O/final_bf16.json $P/${R}_bench_bf16.json
+cp $O/lines1m_fp32.json $P/${R}_lines1m_fp32.json
+cp $O/lines1m_bf16.json $P/${R}_lines1m_bf16.json
+cp $O/st_l1/s_kernel_stats.csv $P/${R}_kernel_stats_fp32_serial.csv
+cp $O/st_l1.json $P/${R}_bench_fp32_serial_under_rocprof.json
+cp $O/st_l4/s_kernel_stats.csv $P/${R}_kernel_stats_fp32_lanes4.csv
+cp $O/traffic_fp32.json $P/${R}_pmc_traffic_fp32.json
+cp $O/mfma_fp32.json $P/${R}_pmc_mfma_fp32.json
+cp $O/mfma32.txt $P/${R}_pmc_mfma_fp32.txt
+cp $O/cfg_fp32.json $P/${R}_configs_3_5_fp32.json
