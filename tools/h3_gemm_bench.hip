@@ -31,12 +31,14 @@ struct H3Gemm {
 
 constexpr int BK = 32;
 
-// 128 x 128 units, 8 waves as 2 (M) x 4 (N), wave tile 64 x 32; three 32 KB stages of K = 32, direct-to-LDS loads
-// issued by every wave (2 + 2 per step); LDS layout and swizzle of wino4_gemm_kernel (a row's K = 32 step is 128 bytes =
-// 8 chunks of 16 bytes: hi(k0-7) lo(k0-7) hi(k8-15) lo(k8-15) ...).
+// Units of (NWM * 32 WMT) x (NWN * 32 WNT) with 8 waves as NWM (M) x NWN (N), wave tile 32 WMT x 32 WNT; three stages of
+// K = 32, direct-to-LDS loads issued by every wave; LDS layout and swizzle of wino4_gemm_kernel (a row's K = 32 step is
+// 128 bytes = 8 chunks of 16 bytes: hi(k0-7) lo(k0-7) hi(k8-15) lo(k8-15) ...).
+template <int WMT, int WNT, int NWM, int NWN>
 __global__ __launch_bounds__(512, 1) void h3_gemm_kernel(const H3Gemm p) {
-  constexpr int NWN = 4, NT = 512, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32, NLA = 2;
-  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];
+  constexpr int NT = 512, TBM = NWM * 32 * WMT, TBN = NWN * 32 * WNT, SA = TBM * 32, SB = TBN * 32, NLA = TBM / 64, NLB = TBN / 64;
+  static_assert(NWM * NWN == 8, "8 waves");
+  extern __shared__ __attribute__((aligned(1024))) float smem[];   // [B0 B1 B2 | A0 A1 A2]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
@@ -45,12 +47,11 @@ __global__ __launch_bounds__(512, 1) void h3_gemm_kernel(const H3Gemm p) {
   const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (L >= NU) return;
   const int my_units = (NU - L + G - 1) / G;
-  unsigned aoff[NLA], boff[2];
+  unsigned off[NLA > NLB ? NLA : NLB];
 #pragma unroll
-  for (int i = 0; i < NLA; i++) {
+  for (int i = 0; i < (NLA > NLB ? NLA : NLB); i++) {
     const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
-    aoff[i] = (unsigned)(((2 * S + (c16 >> 3)) * p.K + (c16 & 7) * 4) * 4);
-    boff[i] = aoff[i];
+    off[i] = (unsigned)(((2 * S + (c16 >> 3)) * p.K + (c16 & 7) * 4) * 4);
   }
   const int nk = p.K / BK;
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;
@@ -74,9 +75,9 @@ __global__ __launch_bounds__(512, 1) void h3_gemm_kernel(const H3Gemm p) {
     const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
     const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
 #pragma unroll
-    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], l_k0 * 4);
+    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, off[i], l_k0 * 4);
 #pragma unroll
-    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * NT * 16, boff[i], l_k0 * 4);
+    for (int i = 0; i < NLB; i++) dma(b_rsrc, sb + i * NT * 16, off[i], l_k0 * 4);
     l_k0 += BK;
     if (l_k0 == p.K) {
       l_k0 = 0;
@@ -85,8 +86,229 @@ __global__ __launch_bounds__(512, 1) void h3_gemm_kernel(const H3Gemm p) {
       bases(l_u, pa, pb, pm);
     }
   };
-  // fragment addresses (floats inside a stage): chunk c of row R sits at (R >> 1) * 64 + ((((R & 1) << 3) | c) ^ ((R >> 1) & 15)) * 4;
-  // k16-step j of a K = 32 step: hi = chunk 4 j + 2 h, lo = the chunk after it (h = lane >> 5)
+  // fragment addresses (floats inside a stage) of the wave's first 32-row sub-tile; sub-tile t is 1024 t floats further
+  int ahi[2], alo[2], bhi[2], blo[2];
+  {
+    const int Ra = wm * (32 * WMT) + (lane & 31), Rb = wn * (32 * WNT) + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = 4 * j + 2 * h;
+      ahi[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | c) ^ ((Ra >> 1) & 15)) << 2);
+      alo[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (c + 1)) ^ ((Ra >> 1) & 15)) << 2);
+      bhi[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | c) ^ ((Rb >> 1) & 15)) << 2);
+      blo[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (c + 1)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[WMT][WNT];
+#pragma unroll
+  for (int mt = 0; mt < WMT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < WNT; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+  int kc = 0, c_u = L;
+#ifdef STORE_DWORD
+  const unsigned moff = (unsigned)((wm * (32 * WMT) + 4 * (lane >> 5)) * p.N + wn * (32 * WNT) + (lane & 31));
+#else
+  const unsigned moff = (unsigned)((wm * (32 * WMT) + (lane & 31)) * p.N + wn * (32 * WNT) + 4 * (lane >> 5));
+#endif
+  const float unscale = p.unscale;
+  auto flush = [&]() __attribute__((always_inline)) {
+    unsigned long long ua, ub, pm;
+    bases(c_u, ua, ub, pm);
+    typedef __attribute__((address_space(1))) f32x4 gf32x4;
+    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
+#ifdef STORE_DWORD
+#pragma unroll
+    for (int mt = 0; mt < WMT; mt++)
+#pragma unroll
+      for (int nt = 0; nt < WNT; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          dst[(mt * 32 + (r & 3) + 8 * (r >> 2)) * p.N + nt * 32] = acc[mt][nt][r] * unscale;
+          acc[mt][nt][r] = 0.f;
+        }
+#else
+#pragma unroll
+    for (int mt = 0; mt < WMT; mt++)
+#pragma unroll
+      for (int nt = 0; nt < WNT; nt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const f32x4 v = {acc[mt][nt][4 * g] * unscale, acc[mt][nt][4 * g + 1] * unscale, acc[mt][nt][4 * g + 2] * unscale,
+                           acc[mt][nt][4 * g + 3] * unscale};
+          *(gf32x4*)(dst + mt * 32 * p.N + nt * 32 + 8 * g) = v;
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[mt][nt][4 * g + e] = 0.f;
+        }
+#endif
+    kc = 0;
+    c_u += G;
+  };
+  f16x8 ah[2][WMT], al[2][WMT], bh[2][WNT], bl[2][WNT];
+  auto frag = [&](int stage, int j, int set) __attribute__((always_inline)) {
+    const float* sa = smem + 3 * SB + stage * SA;
+    const float* sb = smem + stage * SB;
+#pragma unroll
+    for (int t = 0; t < WMT; t++) {
+      ah[set][t] = *(const f16x8*)(sa + ahi[j] + 1024 * t);
+      al[set][t] = *(const f16x8*)(sa + alo[j] + 1024 * t);
+    }
+#pragma unroll
+    for (int t = 0; t < WNT; t++) {
+      bh[set][t] = *(const f16x8*)(sb + bhi[j] + 1024 * t);
+      bl[set][t] = *(const f16x8*)(sb + blo[j] + 1024 * t);
+    }
+  };
+#ifdef STORE_DWORD
+#define MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c, 0, 0, 0)
+#else
+#define MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+  auto mfmas = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < WNT; nt++)
+#pragma unroll
+      for (int mt = 0; mt < WMT; mt++)
+        acc[mt][nt] = MF(bl[set][nt], ah[set][mt], acc[mt][nt]);
+#pragma unroll
+    for (int nt = 0; nt < WNT; nt++)
+#pragma unroll
+      for (int mt = 0; mt < WMT; mt++)
+        acc[mt][nt] = MF(bh[set][nt], al[set][mt], acc[mt][nt]);
+#pragma unroll
+    for (int nt = 0; nt < WNT; nt++)
+#pragma unroll
+      for (int mt = 0; mt < WMT; mt++)
+        acc[mt][nt] = MF(bh[set][nt], ah[set][mt], acc[mt][nt]);
+  };
+  auto step = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
+#ifndef ABL_NOFRAG
+    frag(st, 1, 1);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(0);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef ABL_NODMA
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + NLB));   // vmcnt(one step's loads), lgkmcnt(0)
+#endif
+#ifndef ABL_NOBAR
+    __syncthreads();
+#endif
+#ifndef ABL_NODMA
+    gload(st);
+#endif
+#ifndef ABL_NOFRAG
+    frag(nx, 0, 0);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef ABL_NOSTORE
+    if (++kc == nk) flush();
+#endif
+  };
+  const int nit = my_units * nk;
+  gload(0);
+  gload(1);
+  gload(2);
+  constexpr int LPS = NLA + NLB;
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));
+  __syncthreads();
+  frag(0, 0, 0);
+  frag(0, 1, 1);
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
+// 128 x 128 units with NLW dedicated loader waves (waves 8 .. 8 + NLW - 1): they issue all direct-to-LDS loads of the
+// block (32 per K step) and are the only waves that wait on vmcnt; the eight MFMA waves read fragments, issue MFMAs
+// and store finished products.  One barrier per K step, executed by all waves.
+template <int NLW>
+__global__ __launch_bounds__(512 + 64 * NLW, 1) void h3_gemm_lw_kernel(const H3Gemm p) {
+  constexpr int NWN = 4, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32, QW = 16 / NLW;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
+  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  const int nk = p.K / BK;
+  const int nit = my_units * nk;
+  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) __attribute__((always_inline)) {
+    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
+    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.K * 4ull;
+    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.K * 4ull;
+    m = (unsigned long long)p.M +
+        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
+  };
+  if (wave >= 8) {
+    const int lw = wave - 8;
+    unsigned off[QW];
+#pragma unroll
+    for (int q = 0; q < QW; q++) {
+      const int P = (lw * QW + q) * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      off[q] = (unsigned)(((2 * S + (c16 >> 3)) * p.K + (c16 & 7) * 4) * 4);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)(lw * QW) * 1024u;
+    auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+      unsigned m0_saved;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    };
+    int l_u = L, l_k0 = 0;
+    unsigned long long pa, pb, pm;
+    bases(l_u, pa, pb, pm);
+    auto gload = [&](int stage) __attribute__((always_inline)) {
+      const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
+#pragma unroll
+      for (int q = 0; q < QW; q++) {
+        dma(a_rsrc, sa + q * 1024, off[q], l_k0 * 4);
+        dma(b_rsrc, sb + q * 1024, off[q], l_k0 * 4);
+      }
+      l_k0 += BK;
+      if (l_k0 == p.K) {
+        l_k0 = 0;
+        if (l_u + G < NU) l_u += G;
+        bases(l_u, pa, pb, pm);
+      }
+    };
+    gload(0);
+    gload(1);
+    gload(2);
+    if (QW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (QW == 8) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int st = 0;
+#pragma unroll 1
+    for (int it = 0; it < nit; it++) {
+      if (QW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // step it + 1 landed (step it + 2 may be in flight)
+      else if (QW == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (st == 0) gload(0);
+      else if (st == 1) gload(1);
+      else gload(2);
+      st = st == 2 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  const int wm = wave / NWN, wn = wave % NWN;
   int ahi[2], alo[2], bhi[2], blo[2];
   {
     const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
@@ -150,22 +372,15 @@ __global__ __launch_bounds__(512, 1) void h3_gemm_kernel(const H3Gemm p) {
     __builtin_amdgcn_sched_barrier(0);
     mfma6(0);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // vmcnt(one step's loads), lgkmcnt(0)
-    __syncthreads();
-    gload(st);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
     frag(nx, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     mfma6(1);
     __builtin_amdgcn_sched_barrier(0);
     if (++kc == nk) flush();
   };
-  const int nit = my_units * nk;
-  gload(0);
-  gload(1);
-  gload(2);
-  constexpr int LPS = NLA + 2;
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));
-  __syncthreads();
+  __builtin_amdgcn_s_barrier();
   frag(0, 0, 0);
   int it = 0;
 #pragma unroll 1
@@ -176,7 +391,46 @@ __global__ __launch_bounds__(512, 1) void h3_gemm_kernel(const H3Gemm p) {
   }
   if (it < nit) step(std::integral_constant<int, 0>{});
   if (it + 1 < nit) step(std::integral_constant<int, 1>{});
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
+template <int NLW>
+static float run_lw(const H3Gemm& p, int iters) {
+  auto k = h3_gemm_lw_kernel<NLW>;
+  const int units = p.ncomp * (p.ntile_pad / 128) * (p.N / 128);
+  const int g = units < 256 ? 8 * ((units + 7) / 8) : 256;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k, dim3(g), dim3(512 + 64 * NLW), 0, 0, p);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k, dim3(g), dim3(512 + 64 * NLW), 0, 0, p);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters;
+}
+
+template <int WMT, int WNT, int NWM, int NWN>
+static float run_shape(const H3Gemm& p, int iters) {
+  constexpr int TBM = NWM * 32 * WMT, TBN = NWN * 32 * WNT;
+  const size_t lds = 3 * (size_t)(TBM + TBN) * 32 * 4;
+  if (p.ntile_pad % TBM || p.N % TBN) return -1.f;
+  auto k = h3_gemm_kernel<WMT, WNT, NWM, NWN>;
+  CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int units = p.ncomp * (p.ntile_pad / TBM) * (p.N / TBN);
+  const int g = units < 256 ? 8 * ((units + 7) / 8) : 256;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k, dim3(g), dim3(512), lds, 0, p);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k, dim3(g), dim3(512), lds, 0, p);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -222,21 +476,13 @@ int main(int argc, char** argv) {
     CK(hipMemcpy((char*)dU + c * ub, Bs.data(), ub, hipMemcpyHostToDevice));
   }
   H3Gemm p{dV, dU, dM, M, N, K, ncomp, 1.f / (sa * sb)};
-  const int units = ncomp * (M / 128) * (N / 128);
-  const int g = units < 256 ? 8 * ((units + 7) / 8) : 256;
-  hipEvent_t e0, e1;
-  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(h3_gemm_kernel, dim3(g), dim3(512), 0, 0, p);
-  CK(hipDeviceSynchronize());
-  CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(h3_gemm_kernel, dim3(g), dim3(512), 0, 0, p);
-  CK(hipEventRecord(e1));
-  CK(hipDeviceSynchronize());
-  float ms;
-  CK(hipEventElapsedTime(&ms, e0, e1));
-  ms /= iters;
+  const int shape = argc > 6 ? atoi(argv[6]) : 0;
+  float ms = shape == 1 ? run_shape<2, 2, 4, 2>(p, iters) : shape == 2 ? run_shape<2, 2, 2, 4>(p, iters)
+           : shape == 3 ? run_shape<4, 1, 2, 4>(p, iters) : shape == 12 ? run_lw<2>(p, iters) : shape == 14 ? run_lw<4>(p, iters)
+           : run_shape<2, 1, 2, 4>(p, iters);
+  if (ms < 0) { printf("shape %d does not divide M / N\n", shape); return 0; }
   const double flop = 2.0 * ncomp * M * N * K;
-  printf("ncomp %d M %d N %d K %d: %.4f ms  %.1f TF/s fp32-equivalent (%.1f TF/s of f16 MFMA work), %.2f TB/s of V+U+M\n", ncomp, M, N,
+  printf("shape %d ncomp %d M %d N %d K %d: %.4f ms  %.1f TF/s fp32-equivalent (%.1f TF/s of f16 MFMA work), %.2f TB/s of V+U+M\n", shape, ncomp, M, N,
          K, ms, flop / ms / 1e9, 3 * flop / ms / 1e9, (double)ncomp * (vb + ub + mb) / ms / 1e9);
   // check: component 0 and the last one, a sample of entries against float64
   std::vector<float> C((size_t)M * N);

@@ -80,7 +80,9 @@ int main(int argc, char** argv) {
       rms += s * s;
     }
   rms = std::sqrt(rms / ((double)M * N));
-  const float sa = pow2_scale(A, 8192.f), sb = pow2_scale(B, 8192.f);
+  const float tgt = argc > 3 ? (float)atof(argv[3]) : 8192.f;
+  const float sa = pow2_scale(A, tgt), sb = pow2_scale(B, 8192.f);
+  printf("A scaled to max <= %g\n", tgt);
   std::vector<_Float16> Ah(A.size()), Al(A.size()), Bh(B.size()), Bl(B.size());
   for (size_t i = 0; i < A.size(); i++) { const float x = A[i] * sa; Ah[i] = (_Float16)x; Al[i] = (_Float16)(x - (float)Ah[i]); }
   for (size_t i = 0; i < B.size(); i++) { const float x = B[i] * sb; Bh[i] = (_Float16)x; Bl[i] = (_Float16)(x - (float)Bh[i]); }
