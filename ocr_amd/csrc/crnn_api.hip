@@ -102,6 +102,11 @@ struct crnn_handle {
   float wih_us[2] = {1.f, 1.f}, emb0_us = 1.f;
   uint16_t* d_wih_h3[2] = {};
   uint16_t* d_emb0_h3 = nullptr;
+  // ... and the recurrence (lstm_rec_h3_kernel; CRNN_REC_H3=0 keeps the f32 MFMA kernel)
+  bool rec_h3 = true;
+  std::vector<uint16_t> h_whh3[2];
+  float whh3_unscale[2] = {1.f, 1.f};
+  uint16_t* d_whh3[2] = {};
   int wino4_min_n = 1;
   // classifier arg-max through the certified bf16 pre-filter when the logits are not requested (fp32 path;
   // CRNN_CLS_FILTER=0: plain fp32 GEMM with the fused arg-max)
@@ -300,6 +305,8 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
       if ((rc = upload16(h, h->h_wino4h[i], &h->d_wino4h[i]))) return rc;
     for (int l = 0; l < 2; l++)
       if ((rc = upload16(h, h->h_wih_h3[l], &h->d_wih_h3[l]))) return rc;
+    for (int l = 0; l < 2; l++)
+      if ((rc = upload16(h, h->h_whh3[l], &h->d_whh3[l]))) return rc;
     if ((rc = upload16(h, h->h_emb0_h3, &h->d_emb0_h3))) return rc;
     if ((rc = upload(h, h->h_cls_wnorm, &h->d_cls_wnorm))) return rc;
     for (int l = 0; l < 2; l++) {
@@ -687,6 +694,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync, s);
       if (h->split_ev) (void)hipEventRecord(h->split_ev, s);
     }
+    else if (h->d_whh3[l]) launch_lstm_rec_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], s);
     else launch_lstm_rec(p.xp, h->d_whhp[l], out, tlen, n, g.T, s);
     kmark(h, l ? "lstm1_rec" : "lstm0_rec", recflop, recbytes);
   };
@@ -902,6 +910,7 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   if (const char* e = getenv("CRNN_LIN_GEMM")) h->lin_gemm = atoi(e) != 0;
   if (const char* e = getenv("CRNN_WINO6")) h->wino6 = atoi(e) != 0;
   if (const char* e = getenv("CRNN_F16X3")) h->h3 = atoi(e) != 0;
+  if (const char* e = getenv("CRNN_REC_H3")) h->rec_h3 = atoi(e) != 0;
   if (cfg->precision != CRNN_FP32) h->h3 = false;
   if (const char* e = getenv("CRNN_CLS_FILTER")) h->cls_filter = atoi(e) != 0;
   if (cfg->precision != CRNN_FP32) h->cls_filter = false;
@@ -1087,6 +1096,10 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
       }
       h->h_whhp[l].resize((size_t)2 * 4 * nh * nh);
       pack_whh(whh[0], whh[1], h->h_whhp[l].data());
+      if (h->h3 && h->rec_h3) {
+        h->h_whh3[l].resize((size_t)2 * 4 * nh * nh * 2);
+        h->whh3_unscale[l] = pack_whh_h3(whh[0], whh[1], h->h_whh3[l].data());
+      }
       const std::string pe = "rnn." + std::to_string(l) + ".embedding.";
       const float* ew = find_tensor(m, pe + "weight", {nout, 2 * nh}, err);
       const float* eb = ew ? find_tensor(m, pe + "bias", {nout}, err) : nullptr;
@@ -1568,6 +1581,7 @@ void crnn_destroy(crnn_handle* h) {
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4h[i]);
     for (int l = 0; l < 2; l++) (void)hipFree(h->d_wih_h3[l]);
+    for (int l = 0; l < 2; l++) (void)hipFree(h->d_whh3[l]);
     (void)hipFree(h->d_emb0_h3);
     (void)hipFree(h->d_cls_wnorm);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);

@@ -2511,6 +2511,165 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------
+// The same recurrence on the fp16 MFMA in the f16x3 form (CRNN_F16X3; used by the pipelined device path and by host
+// batches too large for the hidden-split kernel): W_hh as (hi, lo) fp16 pairs with one power-of-two scale, h (|h| < 1)
+// with the fixed scale 2^14, three v_mfma_f32_16x16x32_f16 per fragment pair, fp32 accumulate -- fp32-accurate gates
+// (tools/split_mfma_test.hip) with a matrix phase of 2.6 us instead of 13.7 us per step.  The step is then bound by
+// streaming the 1 MiB of W_hh from L2 (same bytes as fp32).  Same work split as lstm_rec_kernel: one 256-thread
+// workgroup per (direction, 16 lines), wave w owns hidden units [64 w, 64 w + 64) of all four gates (16 row tiles),
+// c in registers, h in LDS (double buffered) as split pairs: line stride 1040 bytes, inside a line [k / 8 mod 4][k / 32]
+// blocks of 8 hi + 8 lo halves, so the 16 lanes of a ds_read_b128 phase hit 16 different 16-byte bank groups.
+// W_hh streams in the order pack_whh_h3 writes: per wave and k-step of 32, the 16 tiles' hi and lo fragments (1 KiB per
+// wave-instruction), through two register sets of 8 tiles each, one half k-step ahead of the MFMAs.
+// ---------------------------------------------------------------------------
+typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
+constexpr int HLS = 1040;
+__global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restrict__ xp, const uint4* __restrict__ whh3,
+                                                          float* __restrict__ rec, const int32_t* __restrict__ tlen,
+                                                          int B, int T, float unscale) {
+  __shared__ __attribute__((aligned(16))) unsigned char hs[2 * LB * HLS];
+  const int dir = blockIdx.y, b0 = blockIdx.x * LB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
+  const int b = b0 + bl;
+  const int Ti = (b < B) ? (tlen ? tlen[b] : T) : 0;
+  int Tmax = 0;
+  for (int j = 0; j < LB; j++) {
+    const int bb = b0 + j;
+    const int tj = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
+    Tmax = tj > Tmax ? tj : Tmax;
+  }
+  for (int i = tid; i < 2 * LB * HLS / 4; i += 256) ((unsigned*)hs)[i] = 0u;
+  float c[4][4], h[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { c[u][r] = 0.f; h[u][r] = 0.f; }
+  // fragment (ks, tile, part) of this wave at wp[((ks * 16 + tile) * 2 + part) * 64]
+  const uint4* wp = whh3 + ((size_t)(dir * 4 + wave) * 8 * 16 * 2) * 64 + lane;
+  uint4 wa[8][2], wb[8][2];
+#pragma unroll
+  for (int t = 0; t < 8; t++) { wa[t][0] = wp[(size_t)(t * 2) * 64]; wa[t][1] = wp[(size_t)(t * 2 + 1) * 64]; }
+  __syncthreads();
+  int cur = 0;
+  for (int s = 0; s < Tmax; s++) {
+    const bool active = s < Ti;
+    const int t = active ? (dir ? (Ti - 1 - s) : s) : 0;
+    const size_t rowi = (size_t)(b < B ? b : 0) * T + t;
+    const float* xrow = xp + rowi * 2048 + dir * 1024 + wave * 64 + q * 4;
+    f32x4 xg[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        xg[g][u] = active ? *(const f32x4*)(xrow + g * 256 + u * 16) : z;
+      }
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* hrow = hs + cur * LB * HLS + bl * HLS + q * 256;
+    auto mfma8 = [&](const uint4 (&w)[8][2], int t0, f16x8r hh, f16x8r hl) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[i][1]), hh, acc[t0 + i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[i][0]), hl, acc[t0 + i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[i][0]), hh, acc[t0 + i], 0, 0, 0);
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < 8; ks++) {
+      const f16x8r hh = *(const f16x8r*)(hrow + ks * 32), hl = *(const f16x8r*)(hrow + ks * 32 + 16);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        wb[i][0] = wp[(size_t)((ks * 16 + 8 + i) * 2) * 64];
+        wb[i][1] = wp[(size_t)((ks * 16 + 8 + i) * 2 + 1) * 64];
+      }
+      mfma8(wa, 0, hh, hl);
+      const int kn = (ks + 1) & 7;      // the last refill wraps to k-step 0 of the NEXT step: it lands under the gate math
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        wa[i][0] = wp[(size_t)((kn * 16 + i) * 2) * 64];
+        wa[i][1] = wp[(size_t)((kn * 16 + i) * 2 + 1) * 64];
+      }
+      mfma8(wb, 8, hh, hl);
+    }
+    unsigned char* hn = hs + (cur ^ 1) * LB * HLS + bl * HLS;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      f32x4 hv4;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (active) {
+          const float ig = sigmoidf_(acc[0 * 4 + u][r] * unscale + xg[0][u][r]);
+          const float fg = sigmoidf_(acc[1 * 4 + u][r] * unscale + xg[1][u][r]);
+          const float gg = tanhf_(acc[2 * 4 + u][r] * unscale + xg[2][u][r]);
+          const float og = sigmoidf_(acc[3 * 4 + u][r] * unscale + xg[3][u][r]);
+          c[u][r] = fg * c[u][r] + ig * gg;
+          h[u][r] = og * tanhf_(c[u][r]);
+        }
+        hv4[r] = h[u][r];
+      }
+      // units k = 64 wave + 16 u + 4 q .. + 4 as split pairs (scale 2^14) into the next h image
+      uint2 hi, lo;
+      split4(hv4, 16384.f, hi, lo);
+      const int ks = wave * 2 + (u >> 1), qq = (u & 1) * 2 + (q >> 1), e = (q & 1) * 4;
+      unsigned char* d = hn + qq * 256 + ks * 32 + e * 2;
+      *(uint2*)d = hi;
+      *(uint2*)(d + 16) = lo;
+      if (active) *(f32x4*)(rec + rowi * 512 + dir * 256 + wave * 64 + u * 16 + q * 4) = hv4;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (int ln = 0; ln < LB; ln++) {   // padding rows (t >= T_i): zero (see lstm_rec_kernel)
+    const int bb = b0 + ln;
+    if (bb >= B) break;
+    const int Tl = tlen ? tlen[bb] : T;
+    for (int r = Tl * 64 + tid; r < T * 64; r += 256)
+      *(f32x4*)(rec + ((size_t)bb * T + (r >> 6)) * 512 + dir * 256 + (r & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+void launch_lstm_rec_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T, float unscale,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(lstm_rec_h3_kernel, dim3((B + LB - 1) / LB, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen, B, T,
+                     unscale);
+}
+
+// W_hh [2][1024][256] -> the fragment order lstm_rec_h3_kernel streams, as (hi, lo) fp16 with ONE power-of-two scale;
+// returns the factor the kernel multiplies its accumulators by: 1 / (scale_W * 2^14)
+float pack_whh_h3(const float* whh_fwd, const float* whh_rev, uint16_t* packed /* 2 * 1024 * 256 * 2 halves */) {
+  float mx = 0.f;
+  for (size_t i = 0; i < (size_t)1024 * 256; i++) mx = fmaxf(mx, fmaxf(fabsf(whh_fwd[i]), fabsf(whh_rev[i])));
+  int e = 0;
+  if (mx > 0.f && std::isfinite(mx)) (void)frexpf(mx, &e);
+  const float sc = ldexpf(1.f, 14 - (e - 1));
+  for (int dir = 0; dir < 2; dir++) {
+    const float* w = dir ? whh_rev : whh_fwd;
+    for (int wave = 0; wave < 4; wave++)
+      for (int ks = 0; ks < 8; ks++)
+        for (int tile = 0; tile < 16; tile++)
+          for (int lane = 0; lane < 64; lane++) {
+            const int g = tile >> 2, u = tile & 3;
+            const int row = g * 256 + wave * 64 + u * 16 + (lane & 15);
+            const int k0 = ks * 32 + 8 * (lane >> 4);
+            uint16_t* dh = packed + ((((size_t)(dir * 4 + wave) * 8 + ks) * 16 + tile) * 2 * 64 + lane) * 8;
+            uint16_t* dl = dh + 64 * 8;
+            for (int j = 0; j < 8; j++) {
+              const float x = w[(size_t)row * 256 + k0 + j] * sc;
+              const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+              memcpy(dh + j, &hi, 2);
+              memcpy(dl + j, &lo, 2);
+            }
+          }
+  }
+  return 1.f / (sc * 16384.f);
+}
+
+// ---------------------------------------------------------------------------
 // Latency form of the recurrence for small batches (one crop per call, a page's worth of crops): the
 // kernel above runs one workgroup per (direction, 16 lines) and is bound by its T sequential steps of
 // ~21 us.  Here FOUR workgroups share a (direction, 16 lines) group: workgroup `part` owns hidden
