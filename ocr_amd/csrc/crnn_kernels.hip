@@ -1590,6 +1590,171 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_h3_kernel(const Wino4Gemm p
 }
 
 
+// The same kernel with NLW dedicated loader waves (waves 8 .. 8 + NLW - 1, as in wino4_gemm_lw_kernel): they issue all
+// direct-to-LDS loads of the block (32 per K step) and are the only waves that wait on vmcnt; the eight MFMA waves read
+// fragments, issue MFMAs and store finished products.  One barrier per K step, executed by all waves.  With the MFMA
+// phase of a step only 384 cycles per wave, one loader wave cannot issue 32 loads in time: four do (8 each).  Measured
+// against the form above (tools/h3_gemm_bench.hip): -9 % at K = 512, -4..6 % at K = 256 and K = 1024, +5 % at K = 64
+// (conv1, which is HBM-bound on its product tensor), so it is used from K = 256.
+template <int NLW>
+__global__ __launch_bounds__(512 + 64 * NLW, 1) void wino4_gemm_h3_lw_kernel(const Wino4Gemm p) {
+  constexpr int NWN = 4, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32, QW = 16 / NLW;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
+  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  const int nk = p.Cin / BK;
+  const int nit = my_units * nk;
+  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) __attribute__((always_inline)) {
+    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
+    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.Cin * 4ull;
+    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.Cin * 4ull;
+    m = (unsigned long long)p.M +
+        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
+  };
+  if (wave >= 8) {
+    const int lw = wave - 8;
+    unsigned off[QW];
+#pragma unroll
+    for (int q = 0; q < QW; q++) {
+      const int P = (lw * QW + q) * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      off[q] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)(lw * QW) * 1024u;
+    auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+      unsigned m0_saved;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    };
+    int l_u = L, l_k0 = 0;
+    unsigned long long pa, pb, pm;
+    bases(l_u, pa, pb, pm);
+    auto gload = [&](int stage) __attribute__((always_inline)) {
+      const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
+#pragma unroll
+      for (int q = 0; q < QW; q++) {
+        dma(a_rsrc, sa + q * 1024, off[q], l_k0 * 4);
+        dma(b_rsrc, sb + q * 1024, off[q], l_k0 * 4);
+      }
+      l_k0 += BK;
+      if (l_k0 == p.Cin) {
+        l_k0 = 0;
+        if (l_u + G < NU) l_u += G;
+        bases(l_u, pa, pb, pm);
+      }
+    };
+    gload(0);
+    gload(1);
+    gload(2);
+    if (QW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (QW == 8) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int st = 0;
+#pragma unroll 1
+    for (int it = 0; it < nit; it++) {
+      if (QW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // step it + 1 landed (step it + 2 may be in flight)
+      else if (QW == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (st == 0) gload(0);
+      else if (st == 1) gload(1);
+      else gload(2);
+      st = st == 2 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  const int wm = wave / NWN, wn = wave % NWN;
+  int ahi[2], alo[2], bhi[2], blo[2];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = 4 * j + 2 * h;
+      ahi[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | c) ^ ((Ra >> 1) & 15)) << 2);
+      alo[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (c + 1)) ^ ((Ra >> 1) & 15)) << 2);
+      bhi[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | c) ^ ((Rb >> 1) & 15)) << 2);
+      blo[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (c + 1)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+  int kc = 0, c_u = L;
+  const unsigned moff = (unsigned)((wm * 64 + (lane & 31)) * p.N + wn * 32 + 4 * (lane >> 5));
+  auto flush = [&]() __attribute__((always_inline)) {
+    unsigned long long ua, ub, pm;
+    bases(c_u, ua, ub, pm);
+    typedef __attribute__((address_space(1))) f32x4 gf32x4;
+    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+        *(gf32x4*)(dst + mt * 32 * p.N + 8 * g) = v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[mt][4 * g + e] = 0.f;
+      }
+    kc = 0;
+    c_u += G;
+  };
+  f16x8 a0h[2], a0l[2], a1h[2], a1l[2], bh[2], bl[2];
+  auto frag = [&](int stage, int j, int set) __attribute__((always_inline)) {
+    const float* sa = smem + 3 * SB + stage * SA;
+    const float* sb = smem + stage * SB;
+    a0h[set] = *(const f16x8*)(sa + ahi[j]);
+    a0l[set] = *(const f16x8*)(sa + alo[j]);
+    a1h[set] = *(const f16x8*)(sa + ahi[j] + 1024);
+    a1l[set] = *(const f16x8*)(sa + alo[j] + 1024);
+    bh[set] = *(const f16x8*)(sb + bhi[j]);
+    bl[set] = *(const f16x8*)(sb + blo[j]);
+  };
+  auto mfma6 = [&](int set) __attribute__((always_inline)) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[set], a0h[set], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[set], a1h[set], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a0l[set], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a1l[set], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a0h[set], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a1h[set], acc[1], 0, 0, 0);
+  };
+  auto step = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
+    frag(st, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
+    frag(nx, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kc == nk) flush();
+  };
+  __builtin_amdgcn_s_barrier();
+  frag(0, 0, 0);
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+}
+
+
 // ---------------------------------------------------------------------------
 // Plain GEMM C = act(A W^T + bias) on the same persistent direct-to-LDS pipeline (LSTM input projections and
 // the classifier: M = lines x T rows, K = 256 / 512).  Units of 128 x 128, unit u = m-tile * ntn + n-tile,
@@ -2054,7 +2219,11 @@ void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
   static const int lw = getenv("CRNN_WINO4_LW") ? atoi(getenv("CRNN_WINO4_LW")) : 1;
   if (p.h3) {   // operands in the f16x3 format (N % 128 == 0 checked by the caller)
     const int u3 = p.ncomp * (p.ntile_pad / 128) * (p.N / 128);
-    hipLaunchKernelGGL(wino4_gemm_h3_kernel, dim3(u3 < 256 ? 8 * ((u3 + 7) / 8) : 256), dim3(512), 0, s, p);
+    static const int h3lw = getenv("CRNN_H3_LW") ? atoi(getenv("CRNN_H3_LW")) : 256;   // loader waves from this K (0 = never)
+    if (h3lw > 0 && p.Cin >= h3lw)
+      hipLaunchKernelGGL((wino4_gemm_h3_lw_kernel<4>), dim3(u3 < 256 ? 8 * ((u3 + 7) / 8) : 256), dim3(768), 0, s, p);
+    else
+      hipLaunchKernelGGL(wino4_gemm_h3_kernel, dim3(u3 < 256 ? 8 * ((u3 + 7) / 8) : 256), dim3(512), 0, s, p);
     return;
   }
   if (nwn == 2) hipLaunchKernelGGL((wino4_gemm_kernel<2>), dim3(g), dim3(256), 0, s, p);
