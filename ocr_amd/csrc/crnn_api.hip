@@ -111,6 +111,7 @@ struct crnn_handle {
   // classifier arg-max through the certified bf16 pre-filter when the logits are not requested (fp32 path;
   // CRNN_CLS_FILTER=0: plain fp32 GEMM with the fused arg-max)
   bool cls_filter = true;
+  bool cls_f16 = false;   // the filter's operands and approximate logits in fp16 instead of bf16 (LSTM head; set at load)
   std::vector<float> h_cls_wnorm;   // ||w_c|| of the classifier rows (rounded up)
   bool wino6 = true;      // conv6 as 1-D Winograd F(4,2) (fp32 path; CRNN_WINO6=0: implicit GEMM)
   bool lin_gemm = true;   // LSTM input projections and classifier on lin_gemm_kernel (CRNN_LIN_GEMM=0: conv_gemm_kernel)
@@ -706,16 +707,16 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     const int N = h->cfg.nclass;
     if (!b16 && h->cls_filter && !want_logits && N >= 512 && N <= 8192 && h->d_cls_wnorm && W16) {
       const int ldl = (N + 7) & ~7;   // bf16 rows of the approximate logits: 16-byte aligned
-      launch_rows_to_bf16(in, p.a16, p.anorm, M, 512, s);
+      launch_rows_to_bf16(in, p.a16, p.anorm, M, 512, s, h->cls_f16);
       kmark(h, "cls_to_bf16", 0, 6.0 * M * 512);
       ConvGemm q{};
       q.A = (const float*)p.a16; q.Wt = (const float*)W16; q.bias = bias; q.C = p.logits;
       q.M = M; q.N = N; q.K = 512; q.ldc = ldl;
       q.Hin = q.Win = q.Hout = q.Wout = 1; q.Cin = 512; q.ks = 1; q.pad = 0; q.act = 0;
-      launch_conv_gemm_bf16(q, true, s);    // approximate logits stored as bf16 in plan.logits
+      launch_conv_gemm_bf16(q, h->cls_f16 ? 2 : 1, s);    // approximate logits stored as bf16 / fp16 in plan.logits
       // bf16 MFMA work: not counted with the f32 MFMA FLOPs (bench.py's executed-FLOP rate is against the f32 peak)
       kmark(h, "cls_filter_bf16", 0, 2.0 * ((double)M * 512 + (double)N * 512) + 2.0 * M * N);
-      launch_cls_select((const uint16_t*)p.logits, in, Wf, bias, p.anorm, h->d_cls_wnorm, p.raw, M, N, 512, ldl, s);
+      launch_cls_select((const uint16_t*)p.logits, in, Wf, bias, p.anorm, h->d_cls_wnorm, p.raw, M, N, 512, ldl, s, h->cls_f16);
       kmark(h, "cls_select", 0, 2.0 * M * N);
       return true;
     }
@@ -1127,7 +1128,12 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
     std::vector<uint16_t>& wdst = h->cfg.lstm ? h->hb_emb_w[1] : h->hb_lin_w;
     const int kk = 2 * nh;
     wdst.resize(wsrc.size());
-    for (size_t i = 0; i < wsrc.size(); i++) wdst[i] = f32_to_bf16_host(wsrc[i]);
+    // fp16 (8x tighter bound, so far fewer candidates to score) when the operands cannot leave its range: the LSTM head's
+    // input is h (|h| < 1) and the weights are checked here; the dense head's input is unbounded: bf16.  CRNN_CLS_F16=0: bf16
+    float wmax = 0.f;
+    for (float v : wsrc) wmax = std::max(wmax, std::fabs(v));
+    h->cls_f16 = h->cfg.lstm && wmax < 30000.f && !(getenv("CRNN_CLS_F16") && atoi(getenv("CRNN_CLS_F16")) == 0);
+    for (size_t i = 0; i < wsrc.size(); i++) wdst[i] = h->cls_f16 ? f32_to_f16_host(wsrc[i]) : f32_to_bf16_host(wsrc[i]);
     h->h_cls_wnorm.assign(((size_t)nclass + 7) / 8 * 8, 0.f);   // padded: the select kernel loads eight at a time
     for (int c = 0; c < nclass; c++) {
       double ss = 0;

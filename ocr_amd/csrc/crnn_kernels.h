@@ -91,7 +91,7 @@ __device__ __forceinline__ void argmax_epilogue(const crnn_f32x16 (&acc)[2][2], 
 // Store epilogue shared by the fp32 and bf16 GEMM kernels: bias + activation (+ per-line width
 // mask) for the wave's 2x2 accumulator tiles.  The activation is a pair of selects, the row guard
 // and the mask are computed once per row, and the masked variant is a separate (wave-uniform) path.
-template <bool OUT_BF16>
+template <int OUT_BF16>   // 0: fp32 output, 1: bf16, 2: fp16
 __device__ __forceinline__ void store_epilogue(const crnn_f32x16 (&acc)[2][2], const ConvGemm& p, float* Cb, int m0,
                                                int n0, int wm, int wn, int lane) {
   const int act = p.act;
@@ -106,7 +106,8 @@ __device__ __forceinline__ void store_epilogue(const crnn_f32x16 (&acc)[2][2], c
   const int rbase = m0 + wm * 64 + 4 * (lane >> 5);
   auto put = [&](long off, float v, bool ok) {
     if (!ok) return;
-    if (OUT_BF16) ((__bf16*)Cb)[off] = (__bf16)v;
+    if (OUT_BF16 == 2) ((_Float16*)Cb)[off] = (_Float16)v;
+    else if (OUT_BF16) ((__bf16*)Cb)[off] = (__bf16)v;
     else Cb[off] = v;
   };
   if (!p.wvalid) {
@@ -268,12 +269,15 @@ void launch_resize_v(const uint8_t* src, const ResizeJob* jobs, const int32_t* c
 
 // bf16 path (crnn_kernels_bf16.hip): bf16 activations and weights, fp32 accumulation ----------
 // ConvGemm is reused with A / Wt (and C when out_bf16) pointing at bf16 data; K % 64 == 0.
-void launch_conv_gemm_bf16(const ConvGemm& p, bool out_bf16, hipStream_t s);
+// out_mode: 0 fp32 output, 1 bf16 output; 2: A, Wt and the output are fp16 (the classifier pre-filter)
+void launch_conv_gemm_bf16(const ConvGemm& p, int out_mode, hipStream_t s);
 // Certified bf16 pre-filter of the classifier arg-max (see crnn_kernels.hip): A fp32 [M][K] -> bf16 copy + row
 // norms; then, from the bf16 GEMM's logits L [M][N] (bf16), idx[row] = exact fp32 arg-max over the certified candidates.
-void launch_rows_to_bf16(const float* A, uint16_t* out, float* norm, int M, int K, hipStream_t s);
+// f16 != 0: fp16 instead of bf16 (8x tighter bound; needs |A|, |W| below the fp16 maximum: the LSTM head, |h| < 1)
+void launch_rows_to_bf16(const float* A, uint16_t* out, float* norm, int M, int K, hipStream_t s, int f16 = 0);
 void launch_cls_select(const uint16_t* L, const float* A, const float* W, const float* bias, const float* anorm,
-                       const float* wnorm, int32_t* idx, int M, int N, int K, int ldl, hipStream_t s);   // ldl % 8 == 0, N <= 8192
+                       const float* wnorm, int32_t* idx, int M, int N, int K, int ldl, hipStream_t s, int f16 = 0);   // ldl % 8 == 0, N <= 8192
+uint16_t f32_to_f16_host(float f);
 void launch_conv0_pool_bf16(const float* in, const float* w9x64, const float* bias, void* out,
                             const int32_t* w1valid, int B, int W, int act, hipStream_t s);
 void launch_pool_2x2s2_bf16(const void* in, void* out, int B, int H, int W, int C, hipStream_t s);

@@ -23,7 +23,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BKH = 64, LDB = 144;  // LDB: LDS row stride in bytes
 
-template <bool OUT_BF16>
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
+template <int OUT_BF16>   // 0: fp32 output, 1: bf16 output, 2: fp16 operands and output (same bytes, v_mfma_f32_32x32x16_f16)
 __global__ __launch_bounds__(256, 3) void conv_gemm_bf16_kernel(const ConvGemm p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,10 +108,19 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16_kernel(const ConvGemm p
       const bf16x8 a1 = *(const bf16x8*)(a + 32 * LDB + ks * 32);
       const bf16x8 b0 = *(const bf16x8*)(b + ks * 32);
       const bf16x8 b1 = *(const bf16x8*)(b + 32 * LDB + ks * 32);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      if (OUT_BF16 == 2) {
+        const f16x8g ha0 = __builtin_bit_cast(f16x8g, a0), ha1 = __builtin_bit_cast(f16x8g, a1);
+        const f16x8g hb0 = __builtin_bit_cast(f16x8g, b0), hb1 = __builtin_bit_cast(f16x8g, b1);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha0, hb0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha0, hb1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1, hb0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1, hb1, acc[1][1], 0, 0, 0);
+      } else {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
   };
   gload();
@@ -134,10 +144,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16_kernel(const ConvGemm p
   store_epilogue<OUT_BF16>(acc, p, p.C, m0, n0, wm, wn, lane);
 }
 
-void launch_conv_gemm_bf16(const ConvGemm& p, bool out_bf16, hipStream_t s) {
+void launch_conv_gemm_bf16(const ConvGemm& p, int out_mode, hipStream_t s) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-  if (out_bf16) hipLaunchKernelGGL(conv_gemm_bf16_kernel<true>, dim3(ntm * ntn), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(conv_gemm_bf16_kernel<false>, dim3(ntm * ntn), dim3(256), 0, s, p);
+  if (out_mode == 2) hipLaunchKernelGGL(conv_gemm_bf16_kernel<2>, dim3(ntm * ntn), dim3(256), 0, s, p);
+  else if (out_mode) hipLaunchKernelGGL(conv_gemm_bf16_kernel<1>, dim3(ntm * ntn), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(conv_gemm_bf16_kernel<0>, dim3(ntm * ntn), dim3(256), 0, s, p);
 }
 
 // ---------------------------------------------------------------------------
