@@ -541,6 +541,17 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     const bool h3 = h3_ok;
     launch_wino4_in((const float*)A, wino_v, n, Hin, Win, Cin, s, h3 ? vs : nullptr);
     kmark(h, wn4[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 36.0 * tiles * Cin));
+    // measured 0.50 ms against 0.32 ms for GEMM + output transform (a 32 x 16 wave tile re-reads its operands
+    // from L2 36 times: 3.9 GB per step), so it stays an opt-in variant
+    static const bool c64 = getenv("CRNN_C64_FUSED") && atoi(getenv("CRNN_C64_FUSED")) != 0;
+    if (h3 && c64 && Cin == 64 && Co % 64 == 0 && pool_out) {
+      // conv1: component GEMMs + output transform + pool1 in one kernel, no product tensor
+      launch_wino4_c64_fused(wino_v, (const float*)h->d_wino4h[layer], vs, h->wino4_us[layer], h->d_conv_b[layer], pool_out,
+                             wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1, s);
+      kmark(h, "conv1_fused_f4", 2.0 * 36 * tiles * Co * Cin,
+            4.0 * (36.0 * ((double)tiles * Cin + (double)Co * Cin) + (double)n * (Hin / 2) * (Win / 2) * Co));
+      return true;
+    }
     Wino4Gemm w{};
     w.V = wino_v; w.U = h3 ? (const float*)h->d_wino4h[layer] : h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp;
     w.N = Co; w.Cin = Cin; w.ncomp = 36; w.h3 = h3;

@@ -200,6 +200,10 @@ void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t
                       int Cout, int act, int pool, hipStream_t s, const float* vs = nullptr, float us = 1.f);
 // fp32 rows [M][K] (K = 256 or 512; false for any other K) -> f16x3 rows + one unscale factor per block of 128 rows
 bool launch_rows_to_f16x3(const float* A, float* out, float* rs, int M, int K, hipStream_t s);
+// conv layers with Cin = 64 (conv1), f16x3 operands: the 36 component GEMMs, the output transform and MaxPool 2x2/2 in one
+// kernel (no product tensor).  V [36][pad(tiles)][64] and U [36][Cout][64] split pairs; y NHWC [B, H/2, W/2, Cout]; Cout % 64 == 0
+void launch_wino4_c64_fused(const float* V, const float* U, const float* vs, float us, const float* bias, float* y,
+                            const int32_t* wvalid, int B, int H, int W, int Cout, int act, hipStream_t s);
 // host: rows of K floats -> the f16x3 format with ONE scale for the whole tensor; returns 1 / scale
 float to_f16x3_host(const float* src, size_t n, uint16_t* dst /* 2 n halves */);
 

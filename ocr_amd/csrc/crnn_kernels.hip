@@ -1756,6 +1756,134 @@ __global__ __launch_bounds__(512 + 64 * NLW, 1) void wino4_gemm_h3_lw_kernel(con
 
 
 // ---------------------------------------------------------------------------
+// conv1 (Cin = 64): the 36 component GEMMs AND the output transform in one kernel, the product tensor M never written.
+// With K = 64 a component GEMM is only two k-steps, so a wave can keep ALL 36 components of its output block in
+// registers: wave = 32 tiles x 16 channels = 36 x 2 accumulators of v_mfma_f32_16x16x32_f16 (288 registers), U fragment
+// as the first operand so that a lane ends up with 4 consecutive channels of one tile for every component -- exactly what
+// the output transform A^T m A needs, in-lane.  Then unscale, bias, activation, width mask and MaxPool 2x2/2 (pool1)
+// as in wino4_out_kernel, and four 16-byte NHWC stores per tile.  Block = 4 waves (one per SIMD) = 32 tiles x 64 channels;
+// the fragments come straight from global memory (V's are shared by the four waves through L1), two components ahead of
+// the MFMAs.  Against the three-kernel form this drops 660 MB of writes and 660 MB of reads per 256-line step.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void wino4_c64_fused_kernel(const uint4* __restrict__ V, const uint4* __restrict__ U,
+                                                                 const float* __restrict__ vs, float us,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 const int32_t* __restrict__ wvalid, int B, int H, int W,
+                                                                 int Co, int act, long ntile_pad, long ntile) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r16 = lane & 15;
+  const int ncb = Co >> 6;
+  const long tb = blockIdx.x / ncb;
+  const int cb = blockIdx.x - (int)(tb * ncb);
+  const long t0 = tb * 32;
+  const int c0 = cb * 64 + wave * 16;
+  // a row (tile or channel) of one component is 64 k = 256 bytes = 16 uint4: k-block kb = k / 8 at uint4 index 2 kb (hi), 2 kb + 1 (lo)
+  const uint4* up = U + ((long)(c0 + r16) * 16 + 2 * q);          // + comp * Co * 16, + ks * 8
+  const uint4* vp = V + ((t0 + r16) * 16 + 2 * q);                // + comp * ntile_pad * 16, + g * 256, + ks * 8
+  f32x4 acc[36][2];
+#pragma unroll
+  for (int c = 0; c < 36; c++) { acc[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  uint4 uf[3][2][2], vf[3][2][2][2];     // [buffer][ks][hi, lo] and [buffer][group][ks][hi, lo]
+  auto fetch = [&](int c, int buf) __attribute__((always_inline)) {
+    const uint4* u = up + (long)c * Co * 16;
+    const uint4* v = vp + (long)c * ntile_pad * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      uf[buf][ks][0] = u[ks * 8];
+      uf[buf][ks][1] = u[ks * 8 + 1];
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        vf[buf][g][ks][0] = v[g * 256 + ks * 8];
+        vf[buf][g][ks][1] = v[g * 256 + ks * 8 + 1];
+      }
+    }
+  };
+  fetch(0, 0);
+  fetch(1, 1);
+#pragma unroll
+  for (int c = 0; c < 36; c++) {
+    const int buf = c % 3;
+    if (c + 2 < 36) fetch(c + 2, (c + 2) % 3);
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads two components ahead (the scheduler would sink them to their uses)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const f16x8 uh = __builtin_bit_cast(f16x8, uf[buf][ks][0]), ul = __builtin_bit_cast(f16x8, uf[buf][ks][1]);
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+        acc[c][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul, __builtin_bit_cast(f16x8, vf[buf][g][ks][0]), acc[c][g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+        acc[c][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh, __builtin_bit_cast(f16x8, vf[buf][g][ks][1]), acc[c][g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+        acc[c][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh, __builtin_bit_cast(f16x8, vf[buf][g][ks][0]), acc[c][g], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // output transform, per tile group: the lane owns tile t = t0 + 16 g + (lane & 15), channels c0 + 4 q .. + 3
+  const int th = H >> 2, tw = (W + 3) >> 2, Wp = W >> 1, Hp = H >> 1;
+  const f32x4 bs = *(const f32x4*)(bias + c0 + 4 * q);
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const long t = t0 + 16 * g + r16;
+    if (t >= ntile) continue;
+    const int tx = (int)(t % tw);
+    const long rr = t / tw;
+    const int ty = (int)(rr % th);
+    const int b = (int)(rr / th);
+    const float rs = vs[t] * us;
+    const int wv = wvalid ? wvalid[b] : W;
+    f32x4 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      f32x4 m[6], cc[4];
+#pragma unroll
+      for (int k = 0; k < 6; k++) m[k] = acc[k * 6 + j][g];
+      wino4_at(m, cc);
+#pragma unroll
+      for (int k = 0; k < 4; k++) s[k][j] = cc[k];
+    }
+    f32x4 o[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      wino4_at(s[k], o[k]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int xx = 4 * tx + j;
+        f32x4 v = o[k][j] * rs + bs;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float x = v[e];
+          if (act == 1) x = x > 0.f ? x : 0.f;
+          else if (act == 2) x = x > 0.f ? x : 0.2f * x;
+          if (xx >= wv) x = 0.f;
+          v[e] = x;
+        }
+        o[k][j] = v;
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < 2; pi++)
+#pragma unroll
+      for (int pj = 0; pj < 2; pj++) {
+        const int xp = 2 * tx + pj;
+        if (xp >= Wp) continue;   // odd W: the last column has no pool window
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          v[e] = fmaxf(fmaxf(o[2 * pi][2 * pj][e], o[2 * pi][2 * pj + 1][e]), fmaxf(o[2 * pi + 1][2 * pj][e], o[2 * pi + 1][2 * pj + 1][e]));
+        *(f32x4*)(y + (((long)b * Hp + 2 * ty + pi) * Wp + xp) * Co + c0 + 4 * q) = v;
+      }
+  }
+}
+
+void launch_wino4_c64_fused(const float* V, const float* U, const float* vs, float us, const float* bias, float* y,
+                            const int32_t* wvalid, int B, int H, int W, int Cout, int act, hipStream_t s) {
+  const long tiles = wino4_tiles(B, H, W), tp = wino4_pad(tiles);
+  hipLaunchKernelGGL(wino4_c64_fused_kernel, dim3((unsigned)((tp / 32) * (Cout / 64))), dim3(256), 0, s, (const uint4*)V,
+                     (const uint4*)U, vs, us, bias, y, wvalid, B, H, W, Cout, act, tp, tiles);
+}
+
+// ---------------------------------------------------------------------------
 // Plain GEMM C = act(A W^T + bias) on the same persistent direct-to-LDS pipeline (LSTM input projections and
 // the classifier: M = lines x T rows, K = 256 / 512).  Units of 128 x 128, unit u = m-tile * ntn + n-tile,
 // block L takes units L, L + G, ...; rows past M / N are clamped in the loader and dropped in the epilogue.
