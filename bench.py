@@ -407,11 +407,12 @@ def main():
     # GEMMs, not the direct form), algorithmic bytes].  An f16x3 kernel executes THREE fp16 MFMA products per fp32
     # product: its roofline is the fp16 MFMA's, with 3x those FLOPs.
     wino4_names = [n for n in order if n.endswith("_f4")]
+    fused4_names = [n for n in order if n.endswith("_fused4")]      # GEMMs + output transform in one kernel (f16x3 only)
     lin_on = fp32 and os.environ.get("CRNN_LIN_GEMM", "1") != "0"
     lin_names = [n for n in order if lin_on and n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
     other_names = [n for n in order if (n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier") or
                                         (n.startswith("conv") and n != "conv0_pool0" and "_win" not in n and "_wout" not in n))
-                   and n not in wino4_names + lin_names]
+                   and n not in wino4_names + fused4_names + lin_names]
 
     def family(kernel, names, what, products, peak):
         ms = sum(acc[n][0] for n in names)
@@ -441,6 +442,10 @@ def main():
             fams.append(family("wino4_gemm_lw_kernel", wino4_names,
                                "Winograd component GEMMs of a layer as one persistent launch of 128x128 units on the f32 MFMA", 1,
                                PEAK_F32_MFMA_TFLOPS))
+    if fused4_names:
+        fams.append(family("wino4_fused_h3_kernel", fused4_names,
+                           "the 36 Winograd component GEMMs of a layer AND its output transform (+ bias, activation, pool1) in one "
+                           "persistent launch of 64x64 units, no product tensor; fp16 MFMA, f16x3 operands", 3, PEAK_BF16_MFMA_TFLOPS))
     if lin_names:
         h3l = [n for n in lin_names if h3 and n != "classifier"]
         if h3l:
@@ -490,7 +495,7 @@ def main():
         if n == "cls_filter_bf16":
             mfma_s += cls_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12)
         elif acc[n][1] and n != "conv0_pool0":
-            is_h3 = h3 and (n in wino4_names or n in ("lstm0_ih", "lstm1_ih", "emb0"))
+            is_h3 = h3 and (n in wino4_names or n in fused4_names or n in ("lstm0_ih", "lstm1_ih", "emb0"))
             mfma_s += (3.0 * acc[n][1] / (PEAK_BF16_MFMA_TFLOPS * 1e12)) if is_h3 else acc[n][1] / ((PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS) * 1e12)
     serial_ms = sum(acc[n][0] for n in order)
     peak = dom["peak"]

@@ -541,26 +541,31 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     const bool h3 = h3_ok;
     launch_wino4_in((const float*)A, wino_v, n, Hin, Win, Cin, s, h3 ? vs : nullptr);
     kmark(h, wn4[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 36.0 * tiles * Cin));
-    // measured 0.50 ms against 0.32 ms for GEMM + output transform (a 32 x 16 wave tile re-reads its operands
-    // from L2 36 times: 3.9 GB per step), so it stays an opt-in variant
-    static const bool c64 = getenv("CRNN_C64_FUSED") && atoi(getenv("CRNN_C64_FUSED")) != 0;
-    if (h3 && c64 && Cin == 64 && Co % 64 == 0 && pool_out) {
-      // conv1: component GEMMs + output transform + pool1 in one kernel, no product tensor
-      launch_wino4_c64_fused(wino_v, (const float*)h->d_wino4h[layer], vs, h->wino4_us[layer], h->d_conv_b[layer], pool_out,
-                             wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1, s);
-      kmark(h, "conv1_fused_f4", 2.0 * 36 * tiles * Co * Cin,
-            4.0 * (36.0 * ((double)tiles * Cin + (double)Co * Cin) + (double)n * (Hin / 2) * (Win / 2) * Co));
-      return true;
+    static const bool fuse21 = !(getenv("CRNN_WINO4_POOL21") && atoi(getenv("CRNN_WINO4_POOL21")) == 0);
+    // the pooled form gives one thread a segment of a tile row: below ~128 lines there are too few of them and the
+    // separate kernels are quicker (n = 1: 0.048 vs 0.02 ms per layer)
+    if (!fuse21 || n < 128) pool21_out = nullptr;
+    // GEMMs + output transform in one kernel (no product tensor): CRNN_WINO4_FUSE = bit mask of layers.  Its 64 x 64
+    // units draw twice the operand bytes per FLOP from L2 of the 128 x 128 GEMM, so it pays where the product tensor
+    // dominates: conv1 0.315 -> 0.20 ms, conv2 0.221 -> 0.217 (and 0.68 GB less HBM traffic), conv4 0.28 -> 0.37
+    static const unsigned fuse_mask = getenv("CRNN_WINO4_FUSE") ? (unsigned)strtoul(getenv("CRNN_WINO4_FUSE"), nullptr, 0) : 0x6u;
+    if (h3 && ((fuse_mask >> layer) & 1u) && Co % 64 == 0 && !pool21_out) {
+      static const char* wf4[7] = {"", "conv1_fused4", "conv2_fused4", "conv3_fused4", "conv4_fused4", "conv5_fused4", ""};
+      Wino4Fused f{};
+      f.V = wino_v; f.U = (const float*)h->d_wino4h[layer]; f.vs = vs; f.bias = h->d_conv_b[layer];
+      f.y = pool_out ? pool_out : (float*)C; f.wvalid = wvalid; f.us = h->wino4_us[layer];
+      f.B = n; f.H = Hin; f.W = Win; f.Cin = Cin; f.N = Co; f.act = h->cfg.leaky_relu ? 2 : 1; f.pool = pool_out ? 1 : 0;
+      f.ntile_pad = (int)tp; f.ntile = (int)tiles;
+      launch_wino4_fused(f, s);
+      const double px = pool_out ? (double)n * (Hin / 2) * (Win / 2) : (double)n * Hin * Win;
+      kmark(h, wf4[layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * (36.0 * ((double)tiles * Cin + (double)Co * Cin) + px * Co));
+      return pool_out != nullptr;
     }
     Wino4Gemm w{};
     w.V = wino_v; w.U = h3 ? (const float*)h->d_wino4h[layer] : h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp;
     w.N = Co; w.Cin = Cin; w.ncomp = 36; w.h3 = h3;
     launch_wino4_gemm(w, s);
     kmark(h, wn4[1][layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * 36 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
-    static const bool fuse21 = !(getenv("CRNN_WINO4_POOL21") && atoi(getenv("CRNN_WINO4_POOL21")) == 0);
-    // the pooled form gives one thread a segment of a tile row: below ~128 lines there are too few of them and the
-    // separate kernels are quicker (n = 1: 0.048 vs 0.02 ms per layer)
-    if (!fuse21 || n < 128) pool21_out = nullptr;
     float* dst = pool_out ? pool_out : (pool21_out ? pool21_out : (float*)C);
     launch_wino4_out(wino_m, h->d_conv_b[layer], dst, wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1,
                      pool_out ? 1 : (pool21_out ? 2 : 0), s, h3 ? vs : nullptr, h->wino4_us[layer]);

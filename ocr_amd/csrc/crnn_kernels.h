@@ -185,6 +185,18 @@ struct Wino4Gemm {
   int ncomp;        // number of component GEMMs: 36 (F(4x4,3x3)); 5 for conv6's 1-D F(4,2)
   int h3;           // operands in the f16x3 format (crnn_kernels.hip): V and U hold (hi, lo) fp16 pairs, M leaves scaled
 };
+// F(4x4,3x3) GEMMs + output transform in one kernel (wino4_fused_h3_kernel; f16x3 operands only)
+struct Wino4Fused {
+  const float* V;      // [36][ntile_pad][Cin], f16x3
+  const float* U;      // [36][N][Cin], f16x3
+  const float* vs;     // [ntile]: 1 / tile scale
+  const float* bias;   // [N]
+  float* y;            // NHWC; pool 0: [B,H,W,N], 1: [B,H/2,W/2,N] (MaxPool 2x2/2 inside the tile)
+  const int32_t* wvalid;
+  float us;            // 1 / weight scale
+  int B, H, W, Cin, N, act, pool, ntile_pad, ntile;
+};
+void launch_wino4_fused(const Wino4Fused& p, hipStream_t s);
 inline long wino4_tiles(int B, int H, int W) { return (long)B * (H / 4) * ((W + 3) / 4); }
 inline long wino4_pad(long tiles) { return (tiles + 127) / 128 * 128; }
 // vs != nullptr: V in the f16x3 format, vs[tile] = 1 / (the tile's scale)
@@ -200,10 +212,6 @@ void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t
                       int Cout, int act, int pool, hipStream_t s, const float* vs = nullptr, float us = 1.f);
 // fp32 rows [M][K] (K = 256 or 512; false for any other K) -> f16x3 rows + one unscale factor per block of 128 rows
 bool launch_rows_to_f16x3(const float* A, float* out, float* rs, int M, int K, hipStream_t s);
-// conv layers with Cin = 64 (conv1), f16x3 operands: the 36 component GEMMs, the output transform and MaxPool 2x2/2 in one
-// kernel (no product tensor).  V [36][pad(tiles)][64] and U [36][Cout][64] split pairs; y NHWC [B, H/2, W/2, Cout]; Cout % 64 == 0
-void launch_wino4_c64_fused(const float* V, const float* U, const float* vs, float us, const float* bias, float* y,
-                            const int32_t* wvalid, int B, int H, int W, int Cout, int act, hipStream_t s);
 // host: rows of K floats -> the f16x3 format with ONE scale for the whole tensor; returns 1 / scale
 float to_f16x3_host(const float* src, size_t n, uint16_t* dst /* 2 n halves */);
 

@@ -1756,131 +1756,245 @@ __global__ __launch_bounds__(512 + 64 * NLW, 1) void wino4_gemm_h3_lw_kernel(con
 
 
 // ---------------------------------------------------------------------------
-// conv1 (Cin = 64): the 36 component GEMMs AND the output transform in one kernel, the product tensor M never written.
-// With K = 64 a component GEMM is only two k-steps, so a wave can keep ALL 36 components of its output block in
-// registers: wave = 32 tiles x 16 channels = 36 x 2 accumulators of v_mfma_f32_16x16x32_f16 (288 registers), U fragment
-// as the first operand so that a lane ends up with 4 consecutive channels of one tile for every component -- exactly what
-// the output transform A^T m A needs, in-lane.  Then unscale, bias, activation, width mask and MaxPool 2x2/2 (pool1)
-// as in wino4_out_kernel, and four 16-byte NHWC stores per tile.  Block = 4 waves (one per SIMD) = 32 tiles x 64 channels;
-// the fragments come straight from global memory (V's are shared by the four waves through L1), two components ahead of
-// the MFMAs.  Against the three-kernel form this drops 660 MB of writes and 660 MB of reads per 256-line step.
+// F(4x4,3x3) component GEMMs AND output transform in one kernel (f16x3 operands): the product tensor M (2.25x the layer's
+// output, written and read back by the three-kernel form) never exists.  Keeping all 36 products of an output block in
+// registers caps the wave tile at 32 x 16 with nothing left (wino4_c64_fused_kernel); instead the output transform is
+// ACCUMULATED while the components go by: with the components taken column by column (j outer, i inner),
+//   T[a]    += A^T[a][i] m_ij        after the K loop of component (i, j)    (4 planes, compile-time coefficients)
+//   Y[a][b] += A^T[b][j] T[a]        after the sixth component of column j   (16 planes)
+// so a wave holds 16 + 4 + 1 planes of its tile: 32 tiles x 16 channels = 168 registers, two waves per SIMD, and the
+// VALU work of one wave (6 operations per product element) runs under the MFMAs of the other.
+// Block = 8 waves = 64 tiles x 64 channels, as 2 (tiles) x 4 (channels); v_mfma_f32_16x16x32_f16 with the U fragment
+// first, so a lane ends with 4 consecutive channels of one tile.  Unit = (64 tiles, 64 channels), all 36 components,
+// K = Cin in steps of 64: 36 Cin / 64 steps through a four-stage direct-to-LDS pipeline (stage = 64 + 64 rows of 256
+// bytes, chunk c of row R at position c ^ (R & 15): conflict-free 16-byte fragment reads), every wave issuing four of
+// the 32 loads of a step.  Persistent: block L takes units L, L + G, ... (XCD-aware order: the channel blocks of one
+// tile block run on one XCD), the loads walk into the next unit while the epilogue of the last one runs.
+// Epilogue: unscale (vs[tile] us), bias, activation, width mask; POOL 0: 16 stores of 16 bytes per tile, 1: MaxPool
+// 2x2/2 inside the tile (pool1).
+// Measured (256 lines; tools/fused_bench.hip): conv1 0.20-0.23 ms against 0.32 for GEMM + output transform, conv2 0.22
+// against 0.22, conv3 / conv4 0.40 against 0.27-0.28, conv5 0.71 against 0.37.  The 64 x 64 unit (all the registers
+// allow) draws twice the operand bytes per FLOP through L1 and LDS of the 128 x 128 GEMM: with the loads ablated conv5
+// takes 0.36 ms, with MFMAs and fragment reads ablated 0.48 (5.4 GB from L2 at 11 TB/s, the rate the 128 x 128 GEMM also
+// tops out at), so it pays only where the product tensor dominates (K <= 128).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void wino4_c64_fused_kernel(const uint4* __restrict__ V, const uint4* __restrict__ U,
-                                                                 const float* __restrict__ vs, float us,
-                                                                 const float* __restrict__ bias, float* __restrict__ y,
-                                                                 const int32_t* __restrict__ wvalid, int B, int H, int W,
-                                                                 int Co, int act, long ntile_pad, long ntile) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r16 = lane & 15;
-  const int ncb = Co >> 6;
-  const long tb = blockIdx.x / ncb;
-  const int cb = blockIdx.x - (int)(tb * ncb);
-  const long t0 = tb * 32;
-  const int c0 = cb * 64 + wave * 16;
-  // a row (tile or channel) of one component is 64 k = 256 bytes = 16 uint4: k-block kb = k / 8 at uint4 index 2 kb (hi), 2 kb + 1 (lo)
-  const uint4* up = U + ((long)(c0 + r16) * 16 + 2 * q);          // + comp * Co * 16, + ks * 8
-  const uint4* vp = V + ((t0 + r16) * 16 + 2 * q);                // + comp * ntile_pad * 16, + g * 256, + ks * 8
-  f32x4 acc[36][2];
+__device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b);
+#ifndef FUSED_ABL
+#define FUSED_ABL 0   // tools/fused_bench.hip: 1 no MFMAs, 2 fragments read once, 4 no loads, 8 no barrier, 16 no transform
+#endif
+template <int POOL>
+__global__ __launch_bounds__(512, 1) void wino4_fused_h3_kernel(const Wino4Fused p) {
+  constexpr int NST = 4, STG = 8192, SVF = 4096, LPS = 4;   // floats per stage; the U rows start SVF floats into a stage
+  __shared__ __attribute__((aligned(1024))) float smem[NST * STG];   // 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, r16 = lane & 15, g = lane >> 4;
+  const int ntn = p.N >> 6, ntm = p.ntile_pad >> 6;
+  const int NU = ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  const int nk = p.Cin >> 6;
+  // ---- loads: instruction q of this wave brings rows 4 I .. 4 I + 3 (I = 2 wave + q) of the V block and of the U block
+  unsigned voff[2];
 #pragma unroll
-  for (int c = 0; c < 36; c++) { acc[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  uint4 uf[3][2][2], vf[3][2][2][2];     // [buffer][ks][hi, lo] and [buffer][group][ks][hi, lo]
-  auto fetch = [&](int c, int buf) __attribute__((always_inline)) {
-    const uint4* u = up + (long)c * Co * 16;
-    const uint4* v = vp + (long)c * ntile_pad * 16;
+  for (int q = 0; q < 2; q++) {
+    const int row = 4 * (2 * wave + q) + g, c = r16 ^ (row & 15);
+    voff[q] = (unsigned)(row * p.Cin * 4 + c * 16);
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 2048u;
+  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned vo, int soff) __attribute__((always_inline)) {
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(vo), "s"(rsrc), "s"(soff) : "memory");
+  };
+  int l_u = L, l_c = 0, l_ks = 0, l_st = 0;   // next (unit, component in issue order, K step) to load and its stage
+  auto gload = [&]() __attribute__((always_inline)) {
+    const int comp = (l_c % 6) * 6 + l_c / 6;   // column by column: i = l_c % 6, j = l_c / 6
+    const int tb = l_u / ntn, cb = l_u - tb * ntn;
+    const unsigned long long pa = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)tb * 64) * p.Cin * 4ull;
+    const unsigned long long pb = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)cb * 64) * p.Cin * 4ull;
+    const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+    const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+    const unsigned sv = lds0 + (unsigned)l_st * (STG * 4), su = sv + SVF * 4;
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      uf[buf][ks][0] = u[ks * 8];
-      uf[buf][ks][1] = u[ks * 8 + 1];
-#pragma unroll
-      for (int g = 0; g < 2; g++) {
-        vf[buf][g][ks][0] = v[g * 256 + ks * 8];
-        vf[buf][g][ks][1] = v[g * 256 + ks * 8 + 1];
+    for (int q = 0; q < 2; q++) {
+      dma(a_rsrc, sv + q * 1024, voff[q], l_ks * 256);
+      dma(b_rsrc, su + q * 1024, voff[q], l_ks * 256);
+    }
+    l_st = (l_st + 1) & (NST - 1);
+    if (++l_ks == nk) {
+      l_ks = 0;
+      if (++l_c == 36) {
+        l_c = 0;
+        if (l_u + G < NU) l_u += G;   // past the last unit: its loads are repeated (valid memory, never read)
       }
     }
   };
-  fetch(0, 0);
-  fetch(1, 1);
+  // ---- fragments: k32 sub-step s of a stage, k-group g: hi chunk 8 s + 2 g, lo chunk the next one
+  int ov[2][2], ou[2][2];   // [sub-step][hi / lo], float offsets inside a stage
+  {
+    const int Rv = wm * 32 + r16, Ru = wn * 16 + r16;
 #pragma unroll
-  for (int c = 0; c < 36; c++) {
-    const int buf = c % 3;
-    if (c + 2 < 36) fetch(c + 2, (c + 2) % 3);
-    __builtin_amdgcn_sched_barrier(0);   // keep the loads two components ahead (the scheduler would sink them to their uses)
+    for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      const f16x8 uh = __builtin_bit_cast(f16x8, uf[buf][ks][0]), ul = __builtin_bit_cast(f16x8, uf[buf][ks][1]);
+      for (int hl = 0; hl < 2; hl++) {
+        const int c = 8 * s2 + 2 * g + hl;
+        ov[s2][hl] = Rv * 64 + ((c ^ (Rv & 15)) << 2);
+        ou[s2][hl] = SVF + Ru * 64 + ((c ^ (Ru & 15)) << 2);
+      }
+  }
+  f32x4 Y[4][4][2], T[4][2], acc[2];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int g = 0; g < 2; g++)
-        acc[c][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul, __builtin_bit_cast(f16x8, vf[buf][g][ks][0]), acc[c][g], 0, 0, 0);
+  for (int a = 0; a < 4; a++)
 #pragma unroll
-      for (int g = 0; g < 2; g++)
-        acc[c][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh, __builtin_bit_cast(f16x8, vf[buf][g][ks][1]), acc[c][g], 0, 0, 0);
+    for (int th = 0; th < 2; th++) {
+      T[a][th] = z4;
 #pragma unroll
-      for (int g = 0; g < 2; g++)
-        acc[c][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh, __builtin_bit_cast(f16x8, vf[buf][g][ks][0]), acc[c][g], 0, 0, 0);
+      for (int b = 0; b < 4; b++) Y[a][b][th] = z4;
     }
+  acc[0] = z4;
+  acc[1] = z4;
+  f16x8 uh[2], ul[2], vh[2][2], vl[2][2];   // [set]([tile half])
+  int c_st = 0;
+  auto frag = [&](int stage, int s2, int set) __attribute__((always_inline)) {
+    const float* sb = smem + stage * STG;
+    uh[set] = *(const f16x8*)(sb + ou[s2][0]);
+    ul[set] = *(const f16x8*)(sb + ou[s2][1]);
+    vh[set][0] = *(const f16x8*)(sb + ov[s2][0]);
+    vl[set][0] = *(const f16x8*)(sb + ov[s2][1]);
+    vh[set][1] = *(const f16x8*)(sb + ov[s2][0] + 1024);   // tile + 16: same swizzle
+    vl[set][1] = *(const f16x8*)(sb + ov[s2][1] + 1024);
+  };
+  auto mfma6 = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int th = 0; th < 2; th++) acc[th] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul[set], vh[set][th], acc[th], 0, 0, 0);
+#pragma unroll
+    for (int th = 0; th < 2; th++) acc[th] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh[set], vl[set][th], acc[th], 0, 0, 0);
+#pragma unroll
+    for (int th = 0; th < 2; th++) acc[th] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh[set], vh[set][th], acc[th], 0, 0, 0);
+  };
+  auto step = [&]() __attribute__((always_inline)) {
+    if (!(FUSED_ABL & 2)) frag(c_st, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
-  }
-  // output transform, per tile group: the lane owns tile t = t0 + 16 g + (lane & 15), channels c0 + 4 q .. + 3
-  const int th = H >> 2, tw = (W + 3) >> 2, Wp = W >> 1, Hp = H >> 1;
-  const f32x4 bs = *(const f32x4*)(bias + c0 + 4 * q);
+    if (!(FUSED_ABL & 1)) mfma6(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // the next step's loads have landed ((NST - 2) LPS may fly)
+    if (!(FUSED_ABL & 8)) __syncthreads();
+    if (!(FUSED_ABL & 4)) gload();                                 // refills the stage just read
+    c_st = (c_st + 1) & (NST - 1);
+    if (!(FUSED_ABL & 2)) frag(c_st, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(FUSED_ABL & 1)) mfma6(1);
+    else if (!(FUSED_ABL & 2)) asm volatile("" ::"v"(uh[0]), "v"(ul[0]), "v"(vh[0][0]), "v"(vl[0][0]), "v"(vh[0][1]), "v"(vl[0][1]), "v"(uh[1]), "v"(ul[1]), "v"(vh[1][0]), "v"(vl[1][0]), "v"(vh[1][1]), "v"(vl[1][1]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  constexpr float AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -0.5f, 0.f},
+                              {0.f, 1.f, 1.f, 4.f, 0.25f, 0.f}, {0.f, 1.f, -1.f, 8.f, -0.125f, 1.f}};
+  auto comp = [&](auto IC) __attribute__((always_inline)) {
+    constexpr int I = decltype(IC)::value;
+#pragma unroll 1
+    for (int ks = 0; ks < nk; ks++) step();
 #pragma unroll
-  for (int g = 0; g < 2; g++) {
-    const long t = t0 + 16 * g + r16;
-    if (t >= ntile) continue;
-    const int tx = (int)(t % tw);
-    const long rr = t / tw;
-    const int ty = (int)(rr % th);
-    const int b = (int)(rr / th);
-    const float rs = vs[t] * us;
-    const int wv = wvalid ? wvalid[b] : W;
-    f32x4 s[4][6];
+    for (int th = 0; th < 2; th++) {
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-      f32x4 m[6], cc[4];
-#pragma unroll
-      for (int k = 0; k < 6; k++) m[k] = acc[k * 6 + j][g];
-      wino4_at(m, cc);
-#pragma unroll
-      for (int k = 0; k < 4; k++) s[k][j] = cc[k];
+      for (int a = 0; a < 4; a++)
+        if (AT[a][I] != 0.f && !(FUSED_ABL & 16)) T[a][th] += AT[a][I] * acc[th];
+      if (!(FUSED_ABL & 16)) acc[th] = z4;
     }
-    f32x4 o[4][4];
+  };
+  const int nty = p.H >> 2, ntx = (p.W + 3) >> 2;
+  auto unit_out = [&](int u) __attribute__((always_inline)) {
+    const int tb = u / ntn, cb = u - tb * ntn;
+    const int c = cb * 64 + wn * 16 + 4 * g;
+    const f32x4 bs = *(const f32x4*)(p.bias + c);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      wino4_at(s[k], o[k]);
+    for (int th = 0; th < 2; th++) {
+      const int t = tb * 64 + wm * 32 + th * 16 + r16;
+      if (t < p.ntile) {
+        const int tx = t % ntx, r = t / ntx, ty = r % nty, b = r / nty;
+        const float rs = p.vs[t] * p.us;
+        const int wv = p.wvalid ? p.wvalid[b] : p.W;
+        auto val = [&](int a, int bb) __attribute__((always_inline)) {
+          f32x4 v = Y[a][bb][th] * rs + bs;
+          const int xx = 4 * tx + bb;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int xx = 4 * tx + j;
-        f32x4 v = o[k][j] * rs + bs;
+          for (int e = 0; e < 4; e++) {
+            float x = v[e];
+            if (p.act == 1) x = x > 0.f ? x : 0.f;
+            else if (p.act == 2) x = x > 0.f ? x : 0.2f * x;
+            if (xx >= wv) x = 0.f;
+            v[e] = x;
+          }
+          return v;
+        };
+        if (POOL == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          float x = v[e];
-          if (act == 1) x = x > 0.f ? x : 0.f;
-          else if (act == 2) x = x > 0.f ? x : 0.2f * x;
-          if (xx >= wv) x = 0.f;
-          v[e] = x;
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++)
+              if (4 * tx + bb < p.W) *(f32x4*)(p.y + (((long)b * p.H + 4 * ty + a) * p.W + 4 * tx + bb) * p.N + c) = val(a, bb);
+        } else if (POOL == 1) {
+          const int Wp = p.W >> 1, Hp = p.H >> 1;
+#pragma unroll
+          for (int pi = 0; pi < 2; pi++)
+#pragma unroll
+            for (int pj = 0; pj < 2; pj++) {
+              const int xp = 2 * tx + pj;
+              if (xp >= Wp) continue;
+              const f32x4 v = max4(max4(val(2 * pi, 2 * pj), val(2 * pi, 2 * pj + 1)), max4(val(2 * pi + 1, 2 * pj), val(2 * pi + 1, 2 * pj + 1)));
+              *(f32x4*)(p.y + (((long)b * Hp + 2 * ty + pi) * Wp + xp) * p.N + c) = v;
+            }
         }
-        o[k][j] = v;
       }
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) Y[a][bb][th] = z4;
     }
+  };
+  // ---- pipeline start: NST steps in flight, the first one landed
 #pragma unroll
-    for (int pi = 0; pi < 2; pi++)
+  for (int i = 0; i < NST; i++) gload();
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // (NST - 1) LPS
+  __syncthreads();
+  frag(0, 0, 0);
+#pragma unroll 1
+  for (int un = 0; un < my_units; un++) {
+#pragma unroll 1
+    for (int j = 0; j < 6; j++) {
+      comp(std::integral_constant<int, 0>{});
+      comp(std::integral_constant<int, 1>{});
+      comp(std::integral_constant<int, 2>{});
+      comp(std::integral_constant<int, 3>{});
+      comp(std::integral_constant<int, 4>{});
+      comp(std::integral_constant<int, 5>{});
+      const float c0 = j < 5 ? 1.f : 0.f;
+      const float c1 = j == 0 || j == 5 ? 0.f : (j == 1 ? 1.f : (j == 2 ? -1.f : (j == 3 ? 2.f : -0.5f)));
+      const float c2 = j == 0 || j == 5 ? 0.f : c1 * c1;
+      const float c3 = j == 0 ? 0.f : (j == 5 ? 1.f : c2 * c1);
 #pragma unroll
-      for (int pj = 0; pj < 2; pj++) {
-        const int xp = 2 * tx + pj;
-        if (xp >= Wp) continue;   // odd W: the last column has no pool window
-        f32x4 v;
+      for (int th = 0; th < 2; th++)
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-          v[e] = fmaxf(fmaxf(o[2 * pi][2 * pj][e], o[2 * pi][2 * pj + 1][e]), fmaxf(o[2 * pi + 1][2 * pj][e], o[2 * pi + 1][2 * pj + 1][e]));
-        *(f32x4*)(y + (((long)b * Hp + 2 * ty + pi) * Wp + xp) * Co + c0 + 4 * q) = v;
-      }
+        for (int a = 0; a < 4; a++) {
+          Y[a][0][th] += c0 * T[a][th];
+          Y[a][1][th] += c1 * T[a][th];
+          Y[a][2][th] += c2 * T[a][th];
+          Y[a][3][th] += c3 * T[a][th];
+          T[a][th] = z4;
+        }
+    }
+    unit_out(L + un * G);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-void launch_wino4_c64_fused(const float* V, const float* U, const float* vs, float us, const float* bias, float* y,
-                            const int32_t* wvalid, int B, int H, int W, int Cout, int act, hipStream_t s) {
-  const long tiles = wino4_tiles(B, H, W), tp = wino4_pad(tiles);
-  hipLaunchKernelGGL(wino4_c64_fused_kernel, dim3((unsigned)((tp / 32) * (Cout / 64))), dim3(256), 0, s, (const uint4*)V,
-                     (const uint4*)U, vs, us, bias, y, wvalid, B, H, W, Cout, act, tp, tiles);
+void launch_wino4_fused(const Wino4Fused& p, hipStream_t s) {
+  const int nu = (p.ntile_pad / 64) * (p.N / 64);
+  const int g = nu < 256 ? 8 * ((nu + 7) / 8) : 256;
+  if (p.pool == 1) hipLaunchKernelGGL((wino4_fused_h3_kernel<1>), dim3(g), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((wino4_fused_h3_kernel<0>), dim3(g), dim3(512), 0, s, p);
 }
 
 // ---------------------------------------------------------------------------

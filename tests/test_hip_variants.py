@@ -55,7 +55,9 @@ VARIANTS = [
     ({"CRNN_LIN_GEMM": "0"}, 1),                              # input projections / classifier on conv_gemm_kernel
     ({"CRNN_F16X3": "0"}, 1),                                 # Winograd GEMMs on the f32 MFMA instead of the f16x3 form
     ({"CRNN_F16X3": "0"}, 4),
-    ({"CRNN_C64_FUSED": "1"}, 1),                             # conv1 as three kernels (product tensor written) instead of the fused one
+    ({"CRNN_WINO4_FUSE": "0"}, 1),                            # conv1 / conv2 as GEMM + output transform (product tensor written)
+    ({"CRNN_WINO4_FUSE": "0x3e"}, 1),                         # every F(4x4) layer on the fused GEMM + output transform kernel
+    ({"CRNN_WINO4_FUSE": "0x3e", "CRNN_WINO4_POOL21": "0"}, 2),   # ... conv3 / conv5 too (pool2 / pool3 as separate kernels)
     ({"CRNN_CLS_F16": "0"}, 1),                               # classifier pre-filter in bf16 instead of fp16
     ({"CRNN_H3_LW": "0"}, 1),                                 # f16x3 Winograd GEMMs without the loader waves
     ({"CRNN_H3_LW": "64"}, 2),                                # ... with loader waves on every layer
@@ -69,7 +71,7 @@ VARIANTS = [
 def test_variant_strings_match_reference_goldens(env, lanes, golden):
     _, M = golden
     e = dict(os.environ)
-    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA", "CRNN_WINOGRAD_F4", "CRNN_WINO4_SHAPE", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_LW", "CRNN_WINO4_POOL21", "CRNN_WINO6", "CRNN_CLS_FILTER", "CRNN_F16X3", "CRNN_REC_H3", "CRNN_LSTM_SPLIT", "CRNN_H3_LW", "CRNN_CLS_F16", "CRNN_C64_FUSED"):
+    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA", "CRNN_WINOGRAD_F4", "CRNN_WINO4_SHAPE", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_LW", "CRNN_WINO4_POOL21", "CRNN_WINO6", "CRNN_CLS_FILTER", "CRNN_F16X3", "CRNN_REC_H3", "CRNN_LSTM_SPLIT", "CRNN_H3_LW", "CRNN_CLS_F16", "CRNN_WINO4_FUSE"):
         e.pop(k, None)
     e.update(env)
     code = CHILD % (ROOT, os.path.join(ROOT, "tests", "golden", "crnn_golden.npz"),
