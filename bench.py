@@ -411,7 +411,7 @@ def main():
     lin_on = fp32 and os.environ.get("CRNN_LIN_GEMM", "1") != "0"
     lin_names = [n for n in order if lin_on and n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
     other_names = [n for n in order if (n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier") or
-                                        (n.startswith("conv") and n != "conv0_pool0" and "_win" not in n and "_wout" not in n))
+                                        (n.startswith("conv") and not n.startswith("conv0_pool0") and "_win" not in n and "_wout" not in n))
                    and n not in wino4_names + fused4_names + lin_names]
 
     def family(kernel, names, what, products, peak):
@@ -485,7 +485,7 @@ def main():
                 pass
             break
     # HBM-bound stages: achieved algorithmic GB/s and the fraction of the 8 TB/s peak (north star: preprocess, arg-max, decode)
-    hbm_names = [n for n in order if (acc[n][1] == 0 and n != "cls_filter_bf16") or n == "conv0_pool0"]
+    hbm_names = [n for n in order if (acc[n][1] == 0 and n != "cls_filter_bf16") or n.startswith("conv0_pool0")]
     hbm_stages = [{"stage": n, "ms": round(acc[n][0], 4), "gbs": round(acc[n][2] / (acc[n][0] * 1e-3) / 1e9, 1),
                    "frac_of_hbm_peak": round(acc[n][2] / (acc[n][0] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} for n in hbm_names]
     # MFMA time at peak of every launch of a step / step time: how busy the matrix pipes are over the whole pipeline
@@ -494,7 +494,7 @@ def main():
     for n in order:
         if n == "cls_filter_bf16":
             mfma_s += cls_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12)
-        elif acc[n][1] and n != "conv0_pool0":
+        elif acc[n][1] and not n.startswith("conv0_pool0"):
             is_h3 = h3 and (n in wino4_names or n in fused4_names or n in ("lstm0_ih", "lstm1_ih", "emb0"))
             mfma_s += (3.0 * acc[n][1] / (PEAK_BF16_MFMA_TFLOPS * 1e12)) if is_h3 else acc[n][1] / ((PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS) * 1e12)
     serial_ms = sum(acc[n][0] for n in order)

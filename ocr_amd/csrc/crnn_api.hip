@@ -68,6 +68,7 @@ struct Lane {
   DevBuf sync;       // time-out word of the hidden-split recurrence
   DevBuf page;       // resident page of this lane (crnn_set_page uses lane 0, crnn_predict_page any free lane)
   int page_h = 0, page_w = 0, page_ch = 0;
+  bool want_p0 = false;        // crnn_debug_stage(.., 0): keep the pooled conv0 output (no conv0 / input transform fusion)
   float* st[11] = {};          // where the stages of the last run live (crnn_debug_stage)
   size_t st_floats[11] = {};
 };
@@ -520,11 +521,17 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
         es * ((double)M * K + (double)N * K) + (C ? ((b16 && out_bf16) ? 2.0 : 4.0) * M * N : 8.0 * M * ((N + 127) / 128)));
 }
 
+// conv1 takes the f16x3 F(4x4) path for a batch of n lines (the condition conv() applies): then conv0 + pool0 can write
+// conv1's V directly (conv0_win4_h3_kernel)
+static bool conv1_on_wino4_h3(const crnn_handle* h, int n) {
+  return h->cfg.precision != CRNN_BF16 && h->h3 && ((h->wino4_mask >> 1) & 1u) && use_wino4(h, n) && h->d_wino4h[1] != nullptr;
+}
+
 // pool_out: where a following MaxPool 2x2/2 would write; the fused Winograd kernel can apply it
 // itself (one tile == one pool window).  Returns true when it did, so the caller skips the pool.
 bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
           int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr, float* pool_out = nullptr,
-          float* pool21_out = nullptr, float* vs = nullptr) {
+          float* pool21_out = nullptr, float* vs = nullptr, bool v_ready = false) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   const bool b16 = h->cfg.precision == CRNN_BF16;
   // (with f16x3 weights only the split form of U exists: a shape that form does not take falls through to the direct conv)
@@ -539,8 +546,10 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     const long tiles = wino4_tiles(n, Hin, Win), tp = wino4_pad(tiles);
     hipStream_t s = tl_cur->stream;
     const bool h3 = h3_ok;
-    launch_wino4_in((const float*)A, wino_v, n, Hin, Win, Cin, s, h3 ? vs : nullptr);
-    kmark(h, wn4[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 36.0 * tiles * Cin));
+    if (!v_ready) {   // (conv1: conv0_win4_h3_kernel may have written V and vs already)
+      launch_wino4_in((const float*)A, wino_v, n, Hin, Win, Cin, s, h3 ? vs : nullptr);
+      kmark(h, wn4[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 36.0 * tiles * Cin));
+    }
     static const bool fuse21 = !(getenv("CRNN_WINO4_POOL21") && atoi(getenv("CRNN_WINO4_POOL21")) == 0);
     // the pooled form gives one thread a segment of a tile row: below ~128 lines there are too few of them and the
     // separate kernels are quicker (n = 1: 0.048 vs 0.02 ms per layer)
@@ -668,10 +677,19 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   const double dn = n;
   const bool b16 = h->cfg.precision == CRNN_BF16;
   const double es = b16 ? 2.0 : 4.0;
-  if (b16) launch_conv0_pool_bf16(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
-  else launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
-  kmark(h, "conv0_pool0", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * dn * 32 * g.W + es * dn * 16 * g.W1 * 64);
-  if (!conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1, p.wv, p.wm, p.p1, nullptr, p.vs)) {
+  // conv0 + pool0 fused with conv1's input transform (CRNN_CONV0_FUSED=0: separate kernels; crnn_debug_stage(.., 0)
+  // asks for the pooled conv0 output itself and gets the separate kernels too)
+  static const bool c0f = !(getenv("CRNN_CONV0_FUSED") && atoi(getenv("CRNN_CONV0_FUSED")) == 0);
+  const bool fuse0 = c0f && !tl_cur->want_p0 && conv1_on_wino4_h3(h, n) && p.wv && p.wm && p.vs && g.W % 2 == 0;
+  if (fuse0) {
+    launch_conv0_win4(p.x, h->d_conv_w[0], h->d_conv_b[0], p.wv, p.vs, m_p0, n, g.W, act, s);
+    kmark(h, "conv0_pool0_win4", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * dn * 32 * g.W + 4.0 * 36.0 * wino4_tiles(n, 16, g.W1) * 64);
+  } else {
+    if (b16) launch_conv0_pool_bf16(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
+    else launch_conv0_pool(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
+    kmark(h, "conv0_pool0", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * dn * 32 * g.W + es * dn * 16 * g.W1 * 64);
+  }
+  if (!conv(h, 1, p.p0, p.c1, m_c1, n, 16, g.W1, 64, 16, g.W1, p.wv, p.wm, p.p1, nullptr, p.vs, fuse0)) {
     if (b16) launch_pool_2x2s2_bf16(p.c1, p.p1, n, 16, g.W1, 128, s);
     else launch_pool_2x2s2(p.c1, p.p1, n, 16, g.W1, 128, s);
     kmark(h, "pool1", 0, es * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
@@ -1504,7 +1522,10 @@ int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const
   int32_t* d_len = d_lab + ((nT + 63) / 64) * 64;
   HIPCHK(h, hipMemcpyAsync(p.x, x, sizeof(float) * (size_t)n * 32 * w, hipMemcpyHostToDevice, tl_cur->stream));
   HIPCHK(h, hipEventRecord(tl_cur->ev[0], tl_cur->stream));
-  if ((rc = run_network(h, g, p, widths, d_lab, d_len, true))) return rc;
+  tl_cur->want_p0 = stage == 0;
+  rc = run_network(h, g, p, widths, d_lab, d_len, true);
+  tl_cur->want_p0 = false;
+  if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
   if ((size_t)out_floats < tl_cur->st_floats[stage]) return fail(h, CRNN_ERR_ARG, "out_host too small for this stage");
   if (h->cfg.precision == CRNN_BF16 && stage != 10) {   // stored as bf16 on the device: widen for the caller

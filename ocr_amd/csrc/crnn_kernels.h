@@ -185,6 +185,9 @@ struct Wino4Gemm {
   int ncomp;        // number of component GEMMs: 36 (F(4x4,3x3)); 5 for conv6's 1-D F(4,2)
   int h3;           // operands in the f16x3 format (crnn_kernels.hip): V and U hold (hi, lo) fp16 pairs, M leaves scaled
 };
+// conv0 + activation + pool0 + conv1's F(4x4) input transform (f16x3 V, per-tile scales) in one kernel; in: [B,32,W] fp32
+void launch_conv0_win4(const float* in, const float* w9x64, const float* bias, float* V, float* vs,
+                       const int32_t* w1valid, int B, int W, int act, hipStream_t s);
 // F(4x4,3x3) GEMMs + output transform in one kernel (wino4_fused_h3_kernel; f16x3 operands only)
 struct Wino4Fused {
   const float* V;      // [36][ntile_pad][Cin], f16x3

@@ -2709,6 +2709,148 @@ __global__ __launch_bounds__(256) void conv0_pool_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------
+// conv0 + activation + pool0 AND conv1's F(4x4,3x3) input transform (f16x3 form) in one kernel: the pooled conv0
+// output (147 MB per 256-line step, written and read back by the two-kernel form) only ever exists as an LDS tile.
+// Block = (line, 4 tile columns): phase 1 computes the 16 x 18 pooled pixels x 64 channels those 16 tiles touch
+// (one column of halo on each side: 12.5 % recomputed) as conv0_pool_kernel does, into LDS (72 KB, two blocks per
+// CU); phase 2 is wino4_in_h3_kernel reading its 6 x 6 patches from LDS: thread = (tile, 4 channels), the tile's
+// scale from the 16 lanes that share it.  Rows -1 and 16 and columns outside [0, min(W/2, w1valid)) are zeros.
+// ---------------------------------------------------------------------------
+constexpr int C0_TXB = 4, C0_PC = 4 * C0_TXB + 2;
+__global__ __launch_bounds__(256, 2) void conv0_win4_h3_kernel(const float* __restrict__ in,
+                                                               const float* __restrict__ w9x64,
+                                                               const float* __restrict__ bias, float* __restrict__ V,
+                                                               float* __restrict__ vs,
+                                                               const int32_t* __restrict__ w1valid, int B, int W,
+                                                               int act, long ntile_pad) {
+  constexpr int IC = 2 * C0_PC + 4;   // input window: columns 2 x1base - 1 ... 2 (x1base + C0_PC - 1) + 2, padded to 40
+  __shared__ __attribute__((aligned(16))) float P[16 * C0_PC * 64];
+  __shared__ __attribute__((aligned(16))) float I[34 * IC];
+  const int W1 = W >> 1, ntx = (W1 + 3) >> 2, ngrp = (ntx + C0_TXB - 1) / C0_TXB;
+  const int cg = threadIdx.x & 15, sub = threadIdx.x >> 4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int blk = blockIdx.x; blk < B * ngrp; blk += gridDim.x) {
+    const int b = blk / ngrp, grp = blk - b * ngrp;
+    const int x1base = 4 * C0_TXB * grp - 1;
+    const int wlim = w1valid ? (w1valid[b] < W1 ? w1valid[b] : W1) : W1;
+    const float* ip = in + (long)b * 32 * W;
+    // ---- phase 0: the zero-padded input window (rows -1 .. 32) into LDS
+    for (int i = threadIdx.x; i < 34 * IC; i += 256) {
+      const int r = i / IC, c = i - r * IC;
+      const int yy = r - 1, xx = 2 * x1base - 1 + c;
+      I[i] = ((unsigned)yy < 32u && (unsigned)xx < (unsigned)W) ? ip[yy * W + xx] : 0.f;
+    }
+    __syncthreads();
+    // ---- phase 1: pooled conv0 pixels into LDS
+    {
+      f32x4 wr[9];
+#pragma unroll
+      for (int t = 0; t < 9; t++) wr[t] = *(const f32x4*)(w9x64 + t * 64 + cg * 4);
+      const f32x4 bs = *(const f32x4*)(bias + cg * 4);
+      for (int pp = sub; pp < 16 * C0_PC; pp += 16) {
+        const int y1 = pp / C0_PC, jx = pp - y1 * C0_PC, x1 = x1base + jx;
+        f32x4 best = z;
+        if ((unsigned)x1 < (unsigned)wlim) {
+          float patch[4][4];
+#pragma unroll
+          for (int dy = 0; dy < 4; dy++) {
+            const float2 lo = *(const float2*)(I + (2 * y1 + dy) * IC + 2 * jx);       // input row 2 y1 - 1 + dy, column 2 x1 - 1
+            const float2 hi = *(const float2*)(I + (2 * y1 + dy) * IC + 2 * jx + 2);
+            patch[dy][0] = lo.x; patch[dy][1] = lo.y; patch[dy][2] = hi.x; patch[dy][3] = hi.y;
+          }
+#pragma unroll
+          for (int py = 0; py < 2; py++)
+#pragma unroll
+            for (int px = 0; px < 2; px++) {
+              f32x4 a = bs;
+#pragma unroll
+              for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) a += wr[ky * 3 + kx] * patch[py + ky][px + kx];
+              if (py == 0 && px == 0) best = a;
+              else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) best[c] = a[c] > best[c] ? a[c] : best[c];
+              }
+            }
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            float v = best[c];
+            if (act == 1) v = v > 0.f ? v : 0.f;
+            else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+            best[c] = v;
+          }
+        }
+        *(f32x4*)(P + pp * 64 + cg * 4) = best;
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: B^T d B of tile (ty, tx), 4 channels per thread.  The tile's scale comes from a BOUND on its largest
+    // component, 49 max|d| (the rows of B^T sum to at most 7 in magnitude), so that every row of the result can be
+    // split and stored as soon as it is computed (144 instead of ~300 live registers: two blocks per CU).  The bound
+    // is loose by 2-3 bits, which only moves the point below which lo parts go subnormal (the fp16 MFMA honours them).
+    {
+      const int ty = sub >> 2, txl = sub & 3, tx = C0_TXB * grp + txl;
+      const bool valid = tx < ntx;   // uniform over the 16 lanes of a tile
+      f32x4 u[6][6];
+      float mx = 0.f;
+      int ro[6];   // six row addresses; the columns are immediate offsets (36 separate addresses get hoisted and spilled)
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int yy = 4 * ty - 1 + k;
+        ro[k] = ((yy < 0 ? 0 : (yy > 15 ? 15 : yy)) * C0_PC + 4 * txl) * 64 + cg * 4;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        f32x4 d[6], c[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const int yy = 4 * ty - 1 + k;
+          d[k] = *(const f32x4*)(P + ro[k] + j * 64);
+          if ((unsigned)yy >= 16u) d[k] = z;
+#pragma unroll
+          for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_fabsf(d[k][e]));
+        }
+        wino4_bt(d, c);
+#pragma unroll
+        for (int k = 0; k < 6; k++) u[k][j] = c[k];
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);   // two columns of loads in flight, not all six (registers)
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      float sc, uns;
+      split_scale_from_max(49.f * mx, sc, uns);
+      const long t = ((long)b * 4 + ty) * ntx + tx;
+      if (valid && cg == 0) vs[t] = uns;
+      float* vrow = V + t * 64;   // component after component: one running pointer, not 36 addresses
+      const long cstride = ntile_pad * 64;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        f32x4 v[6];
+        wino4_bt(u[k], v);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          uint2 hi, lo;
+          split4(v[j], sc, hi, lo);
+          if (valid) store_split_pair(vrow, cg, hi, lo);
+          vrow += cstride;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+void launch_conv0_win4(const float* in, const float* w9x64, const float* bias, float* V, float* vs,
+                       const int32_t* w1valid, int B, int W, int act, hipStream_t s) {
+  const int W1 = W >> 1, ntx = (W1 + 3) >> 2, ngrp = (ntx + C0_TXB - 1) / C0_TXB;
+  long blocks = (long)B * ngrp;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(conv0_win4_h3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, w9x64, bias, V, vs, w1valid, B, W,
+                     act, wino4_pad(wino4_tiles(B, 16, W1)));
+}
+
 void launch_conv0_pool(const float* in, const float* w9x64, const float* bias, float* out,
                        const int32_t* w1valid, int B, int W, int act, hipStream_t s) {
   long npix = (long)B * 16 * (W >> 1);
