@@ -747,7 +747,9 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       q.A = (const float*)p.a16; q.Wt = (const float*)W16; q.bias = bias; q.C = p.logits;
       q.M = M; q.N = N; q.K = 512; q.ldc = ldl;
       q.Hin = q.Win = q.Hout = q.Wout = 1; q.Cin = 512; q.ks = 1; q.pad = 0; q.act = 0;
-      launch_conv_gemm_bf16(q, h->cls_f16 ? 2 : 1, s);    // approximate logits stored as bf16 / fp16 in plan.logits
+      static const bool g16 = !(getenv("CRNN_GEMM16_DMA") && atoi(getenv("CRNN_GEMM16_DMA")) == 0);
+      if (g16 && gemm16_dma_ok(q)) launch_gemm16_dma(q, h->cls_f16 ? 1 : 0, h->cls_f16 ? 2 : 1, s);   // 256 x 256 units, direct-to-LDS
+      else launch_conv_gemm_bf16(q, h->cls_f16 ? 2 : 1, s);    // approximate logits stored as bf16 / fp16 in plan.logits
       // bf16 MFMA work: not counted with the f32 MFMA FLOPs (bench.py's executed-FLOP rate is against the f32 peak)
       kmark(h, "cls_filter_bf16", 0, 2.0 * ((double)M * 512 + (double)N * 512) + 2.0 * M * N);
       launch_cls_select((const uint16_t*)p.logits, in, Wf, bias, p.anorm, h->d_cls_wnorm, p.raw, M, N, 512, ldl, s, h->cls_f16);

@@ -39,6 +39,10 @@ struct ConvGemm {
 void launch_conv_gemm(const ConvGemm& p, hipStream_t s);
 // Plain GEMMs (ks == 1) on the persistent direct-to-LDS kernel; with pmax set the arg-max partials are
 // [M][4 * ceil(N/128)] (one per 32-column group).  lin_gemm_ok: shape fits that kernel.
+// Plain GEMM with 2-byte operands (fp16 / bf16) on the direct-to-LDS pipeline, 256 x 256 units (crnn_kernels_bf16.hip):
+// the classifier pre-filter and the bf16 path's linear layers.  f16: 1 fp16 operands, 0 bf16; out: 0 fp32, 1 bf16, 2 fp16
+bool gemm16_dma_ok(const ConvGemm& p);
+void launch_gemm16_dma(const ConvGemm& p, int f16, int out, hipStream_t s);
 bool lin_gemm_ok(const ConvGemm& p);
 void launch_lin_gemm(const ConvGemm& p, hipStream_t s);
 

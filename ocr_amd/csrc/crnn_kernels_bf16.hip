@@ -152,6 +152,220 @@ void launch_conv_gemm_bf16(const ConvGemm& p, int out_mode, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
+// Plain GEMM C = A W^T + bias with 2-byte operands (fp16 or bf16) on the direct-to-LDS pipeline: the classifier's
+// pre-filter (18176 x 5530 x 512 per 256-line step) and the linear layers of the bf16 path.  Such a GEMM is bound by
+// the rate at which a CU can pull operands through L1 (about 45 GB/s per CU, 11 TB/s over the chip, measured on the
+// Winograd GEMMs), so the unit is as large as the registers allow: 256 x 256 per block, 8 waves as 2 (M) x 4 (N),
+// wave tile 128 x 64 = 8 accumulators of v_mfma_f32_32x32x16 (128 registers).  K in steps of 64 (128 bytes per row,
+// the XOR-swizzled row-pair layout of wino4_gemm_kernel), two 64 KB stages; every wave issues 8 of the 64 loads of a
+// step.  The barrier of a step sits after its last fragment read and before its last 8 MFMAs: behind it the stage is
+// refilled with step + 2, ahead of it every wave has waited for its loads of step + 1.  Persistent, units with the
+// column block fastest (the 22 column blocks of the classifier share their A rows in one XCD's L2).
+// The W fragment is the first MFMA operand, so a lane ends with 4 consecutive columns of one row: 8-byte (2-byte
+// output) or 16-byte (fp32 output) stores.  The bias of a unit comes in by the same direct-to-LDS path (a global
+// load in the epilogue would make the compiler drain every load in flight).
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds16_ptr_t;
+template <int F16, int OUT>   // F16: fp16 operands (else bf16); OUT 0: fp32, 1: bf16, 2: fp16
+__global__ __launch_bounds__(512, 1) void gemm16_dma_kernel(const ConvGemm p) {
+  constexpr int NT = 512, TB = 256, SROW = TB * 32, STG = 2 * SROW;   // floats: one operand's rows of a stage, a stage
+  __shared__ __attribute__((aligned(1024))) float smem[2 * STG + 2 * TB];   // 128 KB + the bias of two units
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntn = (p.N + TB - 1) / TB, ntm = (p.M + TB - 1) / TB;
+  const int NU = ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  const int nk = p.K >> 6;
+  const unsigned lds0 = (unsigned)(size_t)(lds16_ptr_t)smem;
+  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  };
+  auto dma1 = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff) __attribute__((always_inline)) {
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc) : "memory");
+  };
+  const unsigned long long pa = (unsigned long long)p.A, pb = (unsigned long long)p.Wt, pbias = (unsigned long long)p.bias;
+  const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+  const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+  const i32x4 s_rsrc = {(int)(unsigned)pbias, (int)((pbias >> 32) & 0xFFFF), (int)(p.N * 4), 0x00020000};   // past N: zeros
+  // loads: instruction i of this wave fills LDS bytes [(wave * 4 + i) * 1024, +1024) of an operand's stage rows: 16-byte
+  // position P = (wave * 4 + i) * 64 + lane -> row pair S = P >> 4, chunk slot c16 = (P & 15) ^ (S & 15)
+  int l_u = L, l_ks = 0, l_st = 0, l_par = 0;
+  unsigned aoff[4], boff[4];
+  auto unit_offsets = [&]() __attribute__((always_inline)) {
+    const int mt = l_u / ntn, nt = l_u - mt * ntn;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int P = (wave * 4 + i) * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      const int r = 2 * S + (c16 >> 3);
+      int m = mt * TB + r, n = nt * TB + r;
+      m = m < p.M ? m : p.M - 1;
+      n = n < p.N ? n : p.N - 1;
+      aoff[i] = (unsigned)(((long)m * p.K + (c16 & 7) * 8) * 2);
+      boff[i] = (unsigned)(((long)n * p.K + (c16 & 7) * 8) * 2);
+    }
+  };
+  unit_offsets();
+  auto gload = [&]() __attribute__((always_inline)) {
+    const unsigned sa = lds0 + (unsigned)l_st * (STG * 4) + (unsigned)wave * 4096u, sb = sa + SROW * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      dma(a_rsrc, sa + i * 1024, aoff[i], l_ks * 128);
+      dma(b_rsrc, sb + i * 1024, boff[i], l_ks * 128);
+    }
+    if (l_ks == 0 && wave < 4) {   // the unit's 256 bias values, 64 per wave
+      const int nt = l_u % ntn;
+      dma1(s_rsrc, lds0 + 2 * STG * 4 + (unsigned)(l_par * TB + wave * 64) * 4u, (unsigned)((nt * TB + wave * 64 + lane) * 4));
+    }
+    l_st ^= 1;
+    if (++l_ks == nk) {
+      l_ks = 0;
+      l_par ^= 1;
+      if (l_u + G < NU) l_u += G;   // past the last unit: repeats it (never read)
+      unit_offsets();
+    }
+  };
+  // fragments: chunk c of row R at float offset (R >> 1) * 64 + ((((R & 1) << 3) | c) ^ ((R >> 1) & 15)) * 4; k16-step j
+  // of a K = 64 step reads chunk 2 j + (lane >> 5)
+  int fa[4], fb[4];
+  {
+    const int Ra = wm * 128 + (lane & 31), Rb = wn * 64 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = 2 * j + h;
+      fa[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | c) ^ ((Ra >> 1) & 15)) << 2);
+      fb[j] = SROW + (Rb >> 1) * 64 + (((((Rb & 1) << 3) | c) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 af[2][4], bf[2][2];
+  auto frag = [&](int stage, int j, int set) __attribute__((always_inline)) {
+    const float* sb = smem + stage * STG;
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) af[set][mt] = *(const s16x8*)(sb + fa[j] + mt * 1024);   // + 32 rows: same swizzle
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) bf[set][nt] = *(const s16x8*)(sb + fb[j] + nt * 1024);
+  };
+  auto mfma8 = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        if (F16)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8g, bf[set][nt]), __builtin_bit_cast(f16x8g, af[set][mt]), acc[mt][nt], 0, 0, 0);
+        else
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[set][nt]), __builtin_bit_cast(bf16x8, af[set][mt]), acc[mt][nt], 0, 0, 0);
+      }
+  };
+  int c_u = L, c_par = 0, kc = 0;
+  auto flush = [&]() __attribute__((always_inline)) {
+    const int mt0 = c_u / ntn, nt0 = c_u - mt0 * ntn;
+    const float* bl = smem + 2 * STG + c_par * TB + wn * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 bs = *(const f32x4*)(bl + nt * 32 + 8 * g);
+        const int n = nt0 * TB + wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+          const int m = mt0 * TB + wm * 128 + mt * 32 + (lane & 31);
+          f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+          v += bs;
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[mt][nt][4 * g + e] = 0.f;
+          if (m >= p.M || n >= p.N) continue;
+          const long off = (long)m * p.ldc + n;
+          if (n + 3 < p.N) {
+            if (OUT == 0) {
+              typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
+              *(f32x4a*)(p.C + off) = v;
+            } else if (OUT == 1) {
+              typedef __bf16 bf16x4a __attribute__((ext_vector_type(4), aligned(2)));
+              bf16x4a o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              *(bf16x4a*)((__bf16*)p.C + off) = o;
+            } else {
+              typedef _Float16 f16x4a __attribute__((ext_vector_type(4), aligned(2)));
+              f16x4a o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+              *(f16x4a*)((_Float16*)p.C + off) = o;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              if (n + e < p.N) {
+                if (OUT == 0) p.C[off + e] = v[e];
+                else if (OUT == 1) ((__bf16*)p.C)[off + e] = (__bf16)v[e];
+                else ((_Float16*)p.C)[off + e] = (_Float16)v[e];
+              }
+          }
+        }
+      }
+    kc = 0;
+    c_u += G;
+    c_par ^= 1;
+  };
+  const int nit = my_units * nk;
+  gload();
+  gload();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the first step (and its bias) landed; the second may fly
+  __syncthreads();
+  int st = 0;
+  frag(0, 0, 0);
+#pragma unroll 1
+  for (int it = 0; it < nit; it++) {
+    frag(st, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // stage st is in registers; my loads of the next step landed
+    __syncthreads();
+    gload();                                                       // step it + 2 into stage st
+    st ^= 1;
+    frag(st, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kc == nk) flush();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+bool gemm16_dma_ok(const ConvGemm& p) {
+  return p.ks == 1 && p.K % 64 == 0 && p.K >= 128 && !p.pmax && !p.wvalid && p.act == 0 && p.nbatch <= 1 && p.C &&
+         (double)p.M * p.K * 2 < 2.0e9 && (double)p.N * p.K * 2 < 2.0e9 && (long)p.M * p.N >= 256L * 256 * 64;
+}
+// f16: 1 = fp16 operands, 0 = bf16; out: 0 fp32, 1 bf16, 2 fp16
+void launch_gemm16_dma(const ConvGemm& p, int f16, int out, hipStream_t s) {
+  const int nu = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const int g = nu < 256 ? 8 * ((nu + 7) / 8) : 256;
+  if (f16 && out == 2) hipLaunchKernelGGL((gemm16_dma_kernel<1, 2>), dim3(g), dim3(512), 0, s, p);
+  else if (!f16 && out == 1) hipLaunchKernelGGL((gemm16_dma_kernel<0, 1>), dim3(g), dim3(512), 0, s, p);
+  else if (!f16 && out == 0) hipLaunchKernelGGL((gemm16_dma_kernel<0, 0>), dim3(g), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((gemm16_dma_kernel<1, 0>), dim3(g), dim3(512), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
 // conv0 + ReLU + pool0 (fp32 arithmetic on the fp32 input), bf16 NHWC output
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv0_pool_bf16_kernel(const float* __restrict__ in,
