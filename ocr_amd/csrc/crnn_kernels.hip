@@ -1528,6 +1528,9 @@ __global__ __launch_bounds__(512, 1) void wino4_gemm_h3_kernel(const Wino4Gemm p
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+#ifdef H3_NOSTORE
+        if (v[0] == 12345.f)
+#endif
         *(gf32x4*)(dst + mt * 32 * p.N + 8 * g) = v;   // (nontemporal product stores: 20 % slower, measured)
 #pragma unroll
         for (int e = 0; e < 4; e++) acc[mt][4 * g + e] = 0.f;
@@ -1600,6 +1603,7 @@ template <int NLW>
 __global__ __launch_bounds__(512 + 64 * NLW, 1) void wino4_gemm_h3_lw_kernel(const Wino4Gemm p) {
   constexpr int NWN = 4, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32, QW = 16 / NLW;
   __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];
+  __shared__ __attribute__((aligned(16))) float wtile[8 * 32 * 36];   // 36 KB: the product-store transpose tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
   const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
@@ -1690,21 +1694,39 @@ __global__ __launch_bounds__(512 + 64 * NLW, 1) void wino4_gemm_h3_lw_kernel(con
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
   int kc = 0, c_u = L;
-  const unsigned moff = (unsigned)((wm * 64 + (lane & 31)) * p.N + wn * 32 + 4 * (lane >> 5));
+  // Product stores through LDS: from the accumulators a lane would write 16 bytes of 32 different rows (32-byte pieces of
+  // M's 128-byte lines); transposed through a per-wave LDS tile (32 rows x 144 bytes) eight lanes write one full line.
+  // Measured with the stores ablated they cost 0.07 ms of a layer's 0.19-0.30 ms (tools/fused_bench.hip, H3_NOSTORE).
+  float* wst = wtile + wave * (32 * 36);
+  const int wr_off = (lane & 31) * 36 + 4 * (lane >> 5), rd_off = (lane >> 3) * 36 + (lane & 7) * 4;
   auto flush = [&]() __attribute__((always_inline)) {
     unsigned long long ua, ub, pm;
     bases(c_u, ua, ub, pm);
     typedef __attribute__((address_space(1))) f32x4 gf32x4;
-    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
+    __attribute__((address_space(1))) float* dst =
+        (__attribute__((address_space(1))) float*)pm + (unsigned)((wm * 64 + (lane >> 3)) * p.N + wn * 32 + (lane & 7) * 4);
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+    for (int mt = 0; mt < 2; mt++) {
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-        *(gf32x4*)(dst + mt * 32 * p.N + 8 * g) = v;
+        *(f32x4*)(wst + wr_off + 8 * g) = v;
 #pragma unroll
         for (int e = 0; e < 4; e++) acc[mt][4 * g + e] = 0.f;
       }
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave's own tile is in LDS
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const f32x4 v = *(const f32x4*)(wst + rd_off + i * 8 * 36);
+#ifdef H3_NOSTORE
+        if (v[0] == 12345.f)
+#endif
+        *(gf32x4*)(dst + (mt * 32 + i * 8) * p.N) = v;
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // the reads are done before the next pass overwrites the tile
+      __builtin_amdgcn_wave_barrier();
+    }
     kc = 0;
     c_u += G;
   };
@@ -1784,7 +1806,7 @@ __device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b);
 #endif
 template <int POOL>
 __global__ __launch_bounds__(512, 1) void wino4_fused_h3_kernel(const Wino4Fused p) {
-  constexpr int NST = 4, STG = 8192, SVF = 4096, LPS = 4;   // floats per stage; the U rows start SVF floats into a stage
+  constexpr int NST = 4, STG = 8192, SVF = 4096;   // floats per stage; the U rows start SVF floats into a stage
   __shared__ __attribute__((aligned(1024))) float smem[NST * STG];   // 128 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, r16 = lane & 15, g = lane >> 4;

@@ -166,9 +166,12 @@ void launch_conv_gemm_bf16(const ConvGemm& p, int out_mode, hipStream_t s) {
 // load in the epilogue would make the compiler drain every load in flight).
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds16_ptr_t;
+#ifndef G16_ABL
+#define G16_ABL 0   // tools/gemm16_bench.hip: 1 no MFMAs, 2 no loads, 4 no stores
+#endif
 template <int F16, int OUT>   // F16: fp16 operands (else bf16); OUT 0: fp32, 1: bf16, 2: fp16
 __global__ __launch_bounds__(512, 1) void gemm16_dma_kernel(const ConvGemm p) {
-  constexpr int NT = 512, TB = 256, SROW = TB * 32, STG = 2 * SROW;   // floats: one operand's rows of a stage, a stage
+  constexpr int TB = 256, SROW = TB * 32, STG = 2 * SROW;   // floats: one operand's rows of a stage, a stage
   __shared__ __attribute__((aligned(1024))) float smem[2 * STG + 2 * TB];   // 128 KB + the bias of two units
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_dma_kernel(const ConvGemm p) {
     for (int nt = 0; nt < 2; nt++) bf[set][nt] = *(const s16x8*)(sb + fb[j] + nt * 1024);
   };
   auto mfma8 = [&](int set) __attribute__((always_inline)) {
+    if (G16_ABL & 1) { asm volatile("" ::"v"(af[set][0]), "v"(af[set][1]), "v"(af[set][2]), "v"(af[set][3]), "v"(bf[set][0]), "v"(bf[set][1])); return; }
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_dma_kernel(const ConvGemm p) {
           v += bs;
 #pragma unroll
           for (int e = 0; e < 4; e++) acc[mt][nt][4 * g + e] = 0.f;
-          if (m >= p.M || n >= p.N) continue;
+          if (m >= p.M || n >= p.N || ((G16_ABL & 4) && v[0] != 12345.f)) continue;
           const long off = (long)m * p.ldc + n;
           if (n + 3 < p.N) {
             if (OUT == 0) {
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_dma_kernel(const ConvGemm p) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // stage st is in registers; my loads of the next step landed
     __syncthreads();
-    gload();                                                       // step it + 2 into stage st
+    if (!(G16_ABL & 2)) gload();                                   // step it + 2 into stage st
     st ^= 1;
     frag(st, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
