@@ -172,7 +172,7 @@ typedef __attribute__((address_space(3))) void* lds16_ptr_t;
 template <int F16, int OUT>   // F16: fp16 operands (else bf16); OUT 0: fp32, 1: bf16, 2: fp16
 __global__ __launch_bounds__(512, 1) void gemm16_dma_kernel(const ConvGemm p) {
   constexpr int TB = 256, SROW = TB * 32, STG = 2 * SROW;   // floats: one operand's rows of a stage, a stage
-  __shared__ __attribute__((aligned(1024))) float smem[2 * STG + 2 * TB];   // 128 KB + the bias of two units
+  __shared__ __attribute__((aligned(1024))) float smem[2 * STG + 2 * TB + 8 * 16 * 36];   // 128 KB + the bias of two units + 8 store tiles (18 KB)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int ntn = (p.N + TB - 1) / TB, ntm = (p.M + TB - 1) / TB;
@@ -275,9 +275,60 @@ __global__ __launch_bounds__(512, 1) void gemm16_dma_kernel(const ConvGemm p) {
       }
   };
   int c_u = L, c_par = 0, kc = 0;
+  // Epilogue.  2-byte outputs go through a per-wave LDS tile (16 rows x 64 columns, rows padded to 144 bytes) so that
+  // eight lanes write one full 128-byte line of C; straight from the accumulators a lane writes 8 bytes of 32 different
+  // rows (measured: the stores then cost 0.065 ms of the classifier filter's 0.19 ms; tools/gemm16_bench.hip).
+  unsigned char* wt = (unsigned char*)(smem + 2 * STG + 2 * TB) + wave * (16 * 144);
   auto flush = [&]() __attribute__((always_inline)) {
     const int mt0 = c_u / ntn, nt0 = c_u - mt0 * ntn;
     const float* bl = smem + 2 * STG + c_par * TB + wn * 64 + 4 * (lane >> 5);
+    if (OUT != 0 && (p.ldc & 7) == 0) {   // (rows of C 16-byte aligned; columns N .. ldc - 1 may be written: padding)
+      const int r = lane & 15, hrow = (lane >> 4) & 1;   // lanes 0-15 / 16-31 hold rows 0-15 / 16-31 of a 32-row tile
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          if (hrow == half) {
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+              for (int g = 0; g < 4; g++) {
+                const f32x4 bs = *(const f32x4*)(bl + nt * 32 + 8 * g);
+                f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                v += bs;
+                unsigned char* d = wt + r * 144 + (nt * 32 + 8 * g + 4 * (lane >> 5)) * 2;
+                if (OUT == 1) {
+                  typedef __bf16 bf16x4b __attribute__((ext_vector_type(4)));
+                  *(bf16x4b*)d = bf16x4b{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                } else {
+                  typedef _Float16 f16x4b __attribute__((ext_vector_type(4)));
+                  *(f16x4b*)d = f16x4b{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                }
+              }
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const int rr = i * 8 + (lane >> 3);
+            const i32x4 v = *(const i32x4*)(wt + rr * 144 + (lane & 7) * 16);
+            const int m = mt0 * TB + wm * 128 + mt * 32 + half * 16 + rr;
+            const int n = nt0 * TB + wn * 64 + (lane & 7) * 8;
+            if (m < p.M && n < p.N && n + 8 <= p.ldc && !((G16_ABL & 4) && v[0] != 12345)) *(i32x4*)((uint16_t*)p.C + (long)m * p.ldc + n) = v;
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+          for (int r2 = 0; r2 < 16; r2++) acc[mt][nt][r2] = 0.f;
+      }
+      kc = 0;
+      c_u += G;
+      c_par ^= 1;
+      return;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
