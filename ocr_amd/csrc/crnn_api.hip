@@ -114,6 +114,7 @@ struct crnn_handle {
   bool cls_filter = true;
   bool cls_f16 = false;   // the filter's operands and approximate logits in fp16 instead of bf16 (LSTM head; set at load)
   std::vector<float> h_cls_wnorm;   // ||w_c|| of the classifier rows (rounded up)
+  float cls_wnmax = 0.f;            // the largest of them
   bool wino6 = true;      // conv6 as 1-D Winograd F(4,2) (fp32 path; CRNN_WINO6=0: implicit GEMM)
   bool lin_gemm = true;   // LSTM input projections and classifier on lin_gemm_kernel (CRNN_LIN_GEMM=0: conv_gemm_kernel)
   // recurrence: batches of up to split_max lines (4 workgroups per (direction, 16 lines): 256 workgroups, one per CU,
@@ -752,7 +753,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       else launch_conv_gemm_bf16(q, h->cls_f16 ? 2 : 1, s);    // approximate logits stored as bf16 / fp16 in plan.logits
       // bf16 MFMA work: not counted with the f32 MFMA FLOPs (bench.py's executed-FLOP rate is against the f32 peak)
       kmark(h, "cls_filter_bf16", 0, 2.0 * ((double)M * 512 + (double)N * 512) + 2.0 * M * N);
-      launch_cls_select((const uint16_t*)p.logits, in, Wf, bias, p.anorm, h->d_cls_wnorm, p.raw, M, N, 512, ldl, s, h->cls_f16);
+      launch_cls_select((const uint16_t*)p.logits, in, Wf, bias, p.anorm, h->d_cls_wnorm, p.raw, M, N, 512, ldl, s, h->cls_f16, h->cls_wnmax);
       kmark(h, "cls_select", 0, 2.0 * M * N);
       return true;
     }
@@ -1171,10 +1172,12 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
     h->cls_f16 = h->cfg.lstm && wmax < 30000.f && !(getenv("CRNN_CLS_F16") && atoi(getenv("CRNN_CLS_F16")) == 0);
     for (size_t i = 0; i < wsrc.size(); i++) wdst[i] = h->cls_f16 ? f32_to_f16_host(wsrc[i]) : f32_to_bf16_host(wsrc[i]);
     h->h_cls_wnorm.assign(((size_t)nclass + 7) / 8 * 8, 0.f);   // padded: the select kernel loads eight at a time
+    h->cls_wnmax = 0.f;
     for (int c = 0; c < nclass; c++) {
       double ss = 0;
       for (int k = 0; k < kk; k++) ss += (double)wsrc[(size_t)c * kk + k] * wsrc[(size_t)c * kk + k];
       h->h_cls_wnorm[c] = (float)(std::sqrt(ss) * 1.000001);
+      h->cls_wnmax = std::max(h->cls_wnmax, h->h_cls_wnorm[c]);
     }
   }
   if (h->cfg.precision == CRNN_BF16) {

@@ -295,7 +295,7 @@ void launch_conv_gemm_bf16(const ConvGemm& p, int out_mode, hipStream_t s);
 // f16 != 0: fp16 instead of bf16 (8x tighter bound; needs |A|, |W| below the fp16 maximum: the LSTM head, |h| < 1)
 void launch_rows_to_bf16(const float* A, uint16_t* out, float* norm, int M, int K, hipStream_t s, int f16 = 0);
 void launch_cls_select(const uint16_t* L, const float* A, const float* W, const float* bias, const float* anorm,
-                       const float* wnorm, int32_t* idx, int M, int N, int K, int ldl, hipStream_t s, int f16 = 0);   // ldl % 8 == 0, N <= 8192
+                       const float* wnorm, int32_t* idx, int M, int N, int K, int ldl, hipStream_t s, int f16 = 0, float wnmax = 0.f);   // ldl % 8 == 0, N <= 8192
 uint16_t f32_to_f16_host(float f);
 void launch_conv0_pool_bf16(const float* in, const float* w9x64, const float* bias, void* out,
                             const int32_t* w1valid, int B, int W, int act, hipStream_t s);

@@ -3600,7 +3600,7 @@ __global__ __launch_bounds__(256) void cls_select_kernel(const uint16_t* __restr
                                                          const float* __restrict__ W, const float* __restrict__ bias,
                                                          const float* __restrict__ anorm,
                                                          const float* __restrict__ wnorm, int32_t* __restrict__ idx,
-                                                         int M, int N, int K, int ldl) {
+                                                         int M, int N, int K, int ldl, float wnmax) {
   // One wave per row.  The approximate logits are stored as bf16 in rows of ldl (a multiple of 8) elements, so a
   // lane reads eight classes per 16-byte load and the whole row (<= 16 loads per lane, issued together) stays in
   // registers for both steps: best lower bound, then candidates.  The bf16 storage rounding, at most 2^-8 |l|
@@ -3616,6 +3616,16 @@ __global__ __launch_bounds__(256) void cls_select_kernel(const uint16_t* __restr
   for (int ch = 0; ch < CLS_MAXCH; ch++) {
     const int c = ch * 512 + lane * 8;
     v[ch] = c < N ? l[ch * 64 + lane] : uint4{0, 0, 0, 0};
+    if (F16) {   // fp16 form: columns from N on (the row's padding, or nothing at all) read as -inf
+      if (c >= N) v[ch] = uint4{0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u};
+      else if (c + 8 > N) {
+        unsigned w[4] = {v[ch].x, v[ch].y, v[ch].z, v[ch].w};
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          if (c + e >= N) w[e >> 1] = (e & 1) ? ((w[e >> 1] & 0x0000FFFFu) | 0xFC000000u) : ((w[e >> 1] & 0xFFFF0000u) | 0x0000FC00u);
+        v[ch] = uint4{w[0], w[1], w[2], w[3]};
+      }
+    }
   }
   auto val = [&](const uint4& q, int e) {   // element e of the eight bf16 in q
     const unsigned w = e < 2 ? q.x : (e < 4 ? q.y : (e < 6 ? q.z : q.w));
@@ -3639,41 +3649,111 @@ __global__ __launch_bounds__(256) void cls_select_kernel(const uint16_t* __restr
     }
   };
   float lb = -INFINITY;
-#pragma unroll
-  for (int ch = 0; ch < CLS_MAXCH; ch++) {
-    if (ch * 512 < N) {
-      float lo[8], hi[8];
-      bounds(ch, lo, hi);
-#pragma unroll
-      for (int e = 0; e < 8; e++) lb = fmaxf(lb, lo[e]);
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) lb = fmaxf(lb, __shfl_xor(lb, off));
-  // candidate list (wave-uniform), the first 64 kept in LDS
   __shared__ int cand_s[4][64];
+  __shared__ float cand_hi[4][64];
   int* cand = cand_s[threadIdx.x >> 6];
+  float* chi = cand_hi[threadIdx.x >> 6];
   int count = 0;
+  if (!F16) {
 #pragma unroll
-  for (int ch = 0; ch < CLS_MAXCH; ch++) {
-    if (ch * 512 < N) {
-      float lo[8], hi[8];
-      bounds(ch, lo, hi);
-      unsigned mine = 0;
+    for (int ch = 0; ch < CLS_MAXCH; ch++) {
+      if (ch * 512 < N) {
+        float lo[8], hi[8];
+        bounds(ch, lo, hi);
 #pragma unroll
-      for (int e = 0; e < 8; e++) mine |= hi[e] >= lb ? 1u << e : 0u;
-      unsigned long long lanes = __ballot(mine != 0);   // most chunks hold no candidate at all
-      while (lanes) {
-        const int src = __builtin_ctzll(lanes);
-        lanes &= lanes - 1;
-        unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)mine, src);
-        while (bits) {
-          const int e = __builtin_ctz(bits);
-          bits &= bits - 1;
-          if (count < 64 && lane == 0) cand[count] = ch * 512 + src * 8 + e;
-          count++;
+        for (int e = 0; e < 8; e++) lb = fmaxf(lb, lo[e]);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lb = fmaxf(lb, __shfl_xor(lb, off));
+    // candidate list (wave-uniform), the first 64 kept in LDS
+#pragma unroll
+    for (int ch = 0; ch < CLS_MAXCH; ch++) {
+      if (ch * 512 < N) {
+        float lo[8], hi[8];
+        bounds(ch, lo, hi);
+        unsigned mine = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) mine |= hi[e] >= lb ? 1u << e : 0u;
+        unsigned long long lanes = __ballot(mine != 0);   // most chunks hold no candidate at all
+        while (lanes) {
+          const int src = __builtin_ctzll(lanes);
+          lanes &= lanes - 1;
+          unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)mine, src);
+          while (bits) {
+            const int e = __builtin_ctz(bits);
+            bits &= bits - 1;
+            if (count < 64 && lane == 0) cand[count] = ch * 512 + src * 8 + e;
+            count++;
+          }
         }
       }
+    }
+  } else {
+    // fp16 logits: the same candidate set for a tenth of the arithmetic.  With E = the bound's class-dependent part at
+    // the LARGEST weight norm, lo_c >= g(x_c) - E and hi_c <= f(x_c) + E for g(x) = x - k2 |x|, f(x) = x + k2 |x| (both
+    // increasing), so  lb' = g(max x) - E  is a lower bound of max lo, and a group of eight logits whose packed maximum m
+    // has f(m) + E < lb' holds no candidate: one v_pk_max_f16 tree and one compare per group instead of eight bounds.
+    // The few groups that pass get the exact bounds; the class that attains max lo is among them (its hi >= lo >= lb'),
+    // so lb = the largest lo seen is the exact one, and filtering the list by hi >= lb gives the set of the bf16 form.
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    float hm[CLS_MAXCH];
+    float xm = -INFINITY;
+#pragma unroll
+    for (int ch = 0; ch < CLS_MAXCH; ch++) {
+      hm[ch] = -INFINITY;
+      if (ch * 512 < N) {
+        hm[ch] = (float)__builtin_reduce_max(__builtin_bit_cast(h8, v[ch]));
+        xm = fmaxf(xm, hm[ch]);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) xm = fmaxf(xm, __shfl_xor(xm, off));
+    const float E = an * wnmax + (aabs + wabs * wnmax);
+    const float lbq = xm - k2 * __builtin_fabsf(xm) - E;
+    float lbt = -INFINITY;
+#pragma unroll
+    for (int ch = 0; ch < CLS_MAXCH; ch++) {
+      if (ch * 512 < N) {
+        const bool flag = hm[ch] + k2 * __builtin_fabsf(hm[ch]) + E >= lbq;
+        unsigned long long lanes = __ballot(flag);
+        if (lanes) {
+          float lo[8], hi[8];
+          bounds(ch, lo, hi);
+          unsigned mine = 0;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            if (flag && hi[e] >= lbq) { mine |= 1u << e; lbt = fmaxf(lbt, lo[e]); }
+          }
+          lanes = __ballot(mine != 0);
+          while (lanes) {
+            const int src = __builtin_ctzll(lanes);
+            lanes &= lanes - 1;
+            unsigned bits = (unsigned)__builtin_amdgcn_readlane((int)mine, src);
+            while (bits) {
+              const int e = __builtin_ctz(bits);
+              bits &= bits - 1;
+              float hv = hi[0];
+#pragma unroll
+              for (int q = 1; q < 8; q++) hv = e == q ? hi[q] : hv;
+              hv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), src));
+              if (count < 64 && lane == 0) { cand[count] = ch * 512 + src * 8 + e; chi[count] = hv; }
+              count++;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lbt = fmaxf(lbt, __shfl_xor(lbt, off));
+    lb = lbt;
+    if (count <= 64) {   // keep the entries with hi >= lb (lane 0 wrote the list; a longer list is rescanned below with lb)
+      int kept = 0;
+      if (lane == 0) {
+        for (int i = 0; i < count; i++)
+          if (chi[i] >= lb) { cand[kept] = cand[i]; kept++; }
+      }
+      count = __builtin_amdgcn_readfirstlane(kept);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // lane 0's list entries before the other lanes read them
@@ -3745,9 +3825,9 @@ void launch_rows_to_bf16(const float* A, uint16_t* out, float* norm, int M, int 
   hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((M + 3) / 4), dim3(256), 0, s, A, out, norm, M, K, f16);
 }
 void launch_cls_select(const uint16_t* L, const float* A, const float* W, const float* bias, const float* anorm,
-                       const float* wnorm, int32_t* idx, int M, int N, int K, int ldl, hipStream_t s, int f16) {
-  if (f16) hipLaunchKernelGGL(cls_select_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, L, A, W, bias, anorm, wnorm, idx, M, N, K, ldl);
-  else hipLaunchKernelGGL(cls_select_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, L, A, W, bias, anorm, wnorm, idx, M, N, K, ldl);
+                       const float* wnorm, int32_t* idx, int M, int N, int K, int ldl, hipStream_t s, int f16, float wnmax) {
+  if (f16) hipLaunchKernelGGL(cls_select_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, L, A, W, bias, anorm, wnorm, idx, M, N, K, ldl, wnmax);
+  else hipLaunchKernelGGL(cls_select_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, L, A, W, bias, anorm, wnorm, idx, M, N, K, ldl, wnmax);
 }
 uint16_t f32_to_f16_host(float f) {
   const _Float16 h = (_Float16)f;
