@@ -434,10 +434,11 @@ def main():
     fams = []
     if wino4_names:
         if h3:
-            fams.append(family("wino4_gemm_h3_kernel", wino4_names,
-                               "Winograd component GEMMs of a layer -- 36 for F(4x4,3x3) on conv1-5, 5 for conv6's 1-D F(4,2) -- as one "
-                               "persistent launch of 128x128 units on the fp16 MFMA, operands as (hi, lo) fp16 pairs, 3 MFMA products per "
-                               "fp32 product", 3, PEAK_BF16_MFMA_TFLOPS))
+            fams.append(family("wino4_gemm_h3_lw_kernel", wino4_names,
+                               "Winograd component GEMMs of a layer -- 36 for F(4x4,3x3) on the layers that keep a product tensor "
+                               "(conv3-5 by default), 5 for conv6's 1-D F(4,2) -- as one persistent launch of 128x128 units on the fp16 "
+                               "MFMA, operands as (hi, lo) fp16 pairs, 3 MFMA products per fp32 product, loader waves, product stores "
+                               "through LDS (wino4_gemm_h3_kernel below K = 256)", 3, PEAK_BF16_MFMA_TFLOPS))
         else:
             fams.append(family("wino4_gemm_lw_kernel", wino4_names,
                                "Winograd component GEMMs of a layer as one persistent launch of 128x128 units on the f32 MFMA", 1,
