@@ -260,8 +260,10 @@ def main():
 
         def launch(k):
             s = k % NS
+            # --serial: one batch on the device at a time (sync), which also tells the library that its persistent
+            # launches may take every CU (256 blocks instead of the pipelined 192)
             lane = mdl.forward_device(d_lines[k % nslots].data_ptr(), BATCH, WIDTH, d_lab[s].data_ptr(),
-                                      d_len[s].data_ptr())
+                                      d_len[s].data_ptr(), sync=args.serial)
             with torch.cuda.stream(ext[lane]):      # copy-back queued behind the batch on ITS lane
                 h_lab[s].copy_(d_lab[s], non_blocking=True)
                 h_len[s].copy_(d_len[s], non_blocking=True)
@@ -512,6 +514,8 @@ def main():
                                "uint8 lines resident in HBM -> decoded strings on the host" % args.precision,
                    "batch": BATCH, "width": WIDTH, "nclass": NCLASS, "lines_per_step": BATCH * world,
                    "lanes_per_gpu": NL, "gpu_max_hw_queues": _hw_queues(),
+                   "persistent_blocks": {"pipelined_launches": int(os.environ.get("CRNN_PIPELINE_BLOCKS", "192")),
+                                         "alone_on_the_device (the per-kernel table and roofline)": 256},
                    "timed_region": "normalise -> conv stack -> 2x BiLSTM -> classifier arg-max -> CTC collapse on the GPU, label "
                                    "copy-back and string assembly on the host; NOT in it: upload and resize of source images "
                                    "(tools/bench_configs.py measures those: crop replay)",

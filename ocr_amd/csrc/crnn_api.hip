@@ -68,6 +68,7 @@ struct Lane {
   DevBuf sync;       // time-out word of the hidden-split recurrence
   DevBuf page;       // resident page of this lane (crnn_set_page uses lane 0, crnn_predict_page any free lane)
   int page_h = 0, page_w = 0, page_ch = 0;
+  int pblocks = 256;           // blocks of the persistent GEMM launches of the next network run (set_persistent_blocks)
   bool want_p0 = false;        // crnn_debug_stage(.., 0): keep the pooled conv0 output (no conv0 / input transform fusion)
   float* st[11] = {};          // where the stages of the last run live (crnn_debug_stage)
   size_t st_floats[11] = {};
@@ -675,6 +676,8 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   }
   hipStream_t s = tl_cur->stream;
   HIPCHK(h, hipEventRecord(tl_cur->ev[1], s));
+  set_persistent_blocks(tl_cur->pblocks);
+  tl_cur->pblocks = 256;
   const double dn = n;
   const bool b16 = h->cfg.precision == CRNN_BF16;
   const double es = b16 ? 2.0 : 4.0;
@@ -1448,6 +1451,9 @@ int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_
   if (h->kprof) HIPCHK(h, hipEventRecord(tl_cur->kev[0], tl_cur->stream));
   launch_normalize(d_gray, p.x, d_w, n, w, w, tl_cur->stream);
   kmark(h, "normalize", 0, (double)n * 32 * w * 5.0);
+  // several lanes in flight (no sync, not the one-batch-at-a-time profiling mode): leave CUs to the other lanes' kernels
+  static const int pipe_blocks = getenv("CRNN_PIPELINE_BLOCKS") ? atoi(getenv("CRNN_PIPELINE_BLOCKS")) : 192;
+  tl_cur->pblocks = (!sync && !h->kprof && h->nlanes > 1) ? pipe_blocks : 256;
   if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
   if (d_raw)
     HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, tl_cur->stream));

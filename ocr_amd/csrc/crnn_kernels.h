@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace crnn {
 
@@ -11,6 +12,22 @@ namespace crnn {
 //   C[m][n] = act( sum_k A_im2col[m][k] * Wt[n][k] + bias[n] ),  m = (b, y, x) of the OUTPUT
 // A is NHWC [B,Hin,Win,Cin]; K = ks*ks*Cin ordered (ky,kx,ci); a plain GEMM is
 // the 1x1 case with Hin=Win=Hout=Wout=1, Cin=K.
+// Blocks of a persistent GEMM launch (a multiple of 8 for the XCD-aware unit order): 256, one per CU, when the caller has
+// the device to itself.  Launches of the pipelined device path (several lanes in flight) use fewer (192 by default):
+// a launch that claims every CU makes the kernels of the other lanes -- the 32-CU recurrences in particular -- and its own
+// late blocks queue behind one another; measured 96 k -> 100 k lines/s (bench.py, 4 lanes) for 160-192 blocks, although
+// each GEMM alone on the device is 15 % slower with 192.  set_persistent_blocks is per host thread (the API sets it
+// before the launches of a network run); CRNN_PERSISTENT_BLOCKS overrides both.
+inline thread_local int g_persistent_blocks = 256;
+inline void set_persistent_blocks(int g) {
+  static const int forced = [] {
+    const char* e = getenv("CRNN_PERSISTENT_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 8 && v <= 1024 ? v / 8 * 8 : 0;
+  }();
+  g_persistent_blocks = forced ? forced : (g >= 8 && g <= 1024 ? g / 8 * 8 : 256);
+}
+inline int persistent_blocks() { return g_persistent_blocks; }
 struct ConvGemm {
   const float* A;
   const float* Wt;    // [N][K]

@@ -2014,7 +2014,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_h3_kernel(const Wino4Fused
 
 void launch_wino4_fused(const Wino4Fused& p, hipStream_t s) {
   const int nu = (p.ntile_pad / 64) * (p.N / 64);
-  const int g = nu < 256 ? 8 * ((nu + 7) / 8) : 256;
+  const int g = nu < persistent_blocks() ? 8 * ((nu + 7) / 8) : persistent_blocks();
   if (p.pool == 1) hipLaunchKernelGGL((wino4_fused_h3_kernel<1>), dim3(g), dim3(512), 0, s, p);
   else hipLaunchKernelGGL((wino4_fused_h3_kernel<0>), dim3(g), dim3(512), 0, s, p);
 }
@@ -2456,7 +2456,7 @@ bool lin_gemm_ok(const ConvGemm& p) {
 void launch_lin_gemm(const ConvGemm& p0, hipStream_t s) {
   ConvGemm p = p0;
   const int ntn = (p.N + 127) / 128, ntm = (p.M + 127) / 128, units = ntm * ntn;
-  const int g = units < 256 ? 8 * ((units + 7) / 8) : 256;
+  const int g = units < persistent_blocks() ? 8 * ((units + 7) / 8) : persistent_blocks();
   // column groups: the fewest whose slice of W (N/gn x K floats) fits an XCD's 4 MB L2 with room for A tiles,
   // provided every XCD's rectangle still has at least one unit per block
   p.gn = 0;
@@ -2485,9 +2485,9 @@ void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
     const int u3 = p.ncomp * (p.ntile_pad / 128) * (p.N / 128);
     static const int h3lw = getenv("CRNN_H3_LW") ? atoi(getenv("CRNN_H3_LW")) : 256;   // loader waves from this K (0 = never)
     if (h3lw > 0 && p.Cin >= h3lw)
-      hipLaunchKernelGGL((wino4_gemm_h3_lw_kernel<4>), dim3(u3 < 256 ? 8 * ((u3 + 7) / 8) : 256), dim3(768), 0, s, p);
+      hipLaunchKernelGGL((wino4_gemm_h3_lw_kernel<4>), dim3(u3 < persistent_blocks() ? 8 * ((u3 + 7) / 8) : persistent_blocks()), dim3(768), 0, s, p);
     else
-      hipLaunchKernelGGL(wino4_gemm_h3_kernel, dim3(u3 < 256 ? 8 * ((u3 + 7) / 8) : 256), dim3(512), 0, s, p);
+      hipLaunchKernelGGL(wino4_gemm_h3_kernel, dim3(u3 < persistent_blocks() ? 8 * ((u3 + 7) / 8) : persistent_blocks()), dim3(512), 0, s, p);
     return;
   }
   if (nwn == 2) hipLaunchKernelGGL((wino4_gemm_kernel<2>), dim3(g), dim3(256), 0, s, p);

@@ -413,7 +413,7 @@ bool gemm16_dma_ok(const ConvGemm& p) {
 // f16: 1 = fp16 operands, 0 = bf16; out: 0 fp32, 1 bf16, 2 fp16
 void launch_gemm16_dma(const ConvGemm& p, int f16, int out, hipStream_t s) {
   const int nu = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  const int g = nu < 256 ? 8 * ((nu + 7) / 8) : 256;
+  const int g = nu < persistent_blocks() ? 8 * ((nu + 7) / 8) : persistent_blocks();
   if (f16 && out == 2) hipLaunchKernelGGL((gemm16_dma_kernel<1, 2>), dim3(g), dim3(512), 0, s, p);
   else if (!f16 && out == 1) hipLaunchKernelGGL((gemm16_dma_kernel<0, 1>), dim3(g), dim3(512), 0, s, p);
   else if (!f16 && out == 0) hipLaunchKernelGGL((gemm16_dma_kernel<0, 0>), dim3(g), dim3(512), 0, s, p);
