@@ -823,9 +823,9 @@ __device__ __forceinline__ void store_split_pair(float* rowbase, int c4, uint2 h
 // F(4x4,3x3) input transform writing the f16x3 format: as wino4_in_kernel, plus the tile's scale (the largest |v| over
 // its 36 components and all channels: the C/4 threads of a tile are consecutive lanes, or two waves for C = 512) to
 // vs[tile] (as 1 / s).  The block-level loop bound is uniform, so every thread reaches the barrier.
-__global__ __launch_bounds__(256) void wino4_in_h3_kernel(const float* __restrict__ x, float* __restrict__ V,
-                                                          float* __restrict__ vs, int B, int H, int W, int C,
-                                                          long ntile_pad) {
+__global__ __launch_bounds__(256, 2) void wino4_in_h3_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                             float* __restrict__ vs, int B, int H, int W, int C,
+                                                             long ntile_pad) {
   __shared__ float wmax[2][4];
   const int th = H >> 2, tw = (W + 3) >> 2, C4 = C >> 2;
   const long total = (long)B * th * tw * C4;
@@ -842,6 +842,7 @@ __global__ __launch_bounds__(256) void wino4_in_h3_kernel(const float* __restric
     const int ty = (int)(r % th);
     const int b = (int)(r / th);
     f32x4 u[6][6];
+    float mx = 0.f;   // largest |d| of the patch: the tile's scale comes from the bound 49 max|d| on its components
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       const int xx = 4 * tx - 1 + j;
@@ -853,22 +854,12 @@ __global__ __launch_bounds__(256) void wino4_in_h3_kernel(const float* __restric
         const int yy = 4 * ty - 1 + k;
         const bool ok = valid && okx && (unsigned)yy < (unsigned)H;
         d[k] = ok ? *(const f32x4*)(px + (long)yy * W * C) : z;
+#pragma unroll
+        for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_fabsf(d[k][e]));
       }
       wino4_bt(d, c);
 #pragma unroll
       for (int k = 0; k < 6; k++) u[k][j] = c[k];
-    }
-    float mx = 0.f;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      f32x4 v[6];
-      wino4_bt(u[k], v);
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        u[k][j] = v[j];
-#pragma unroll
-        for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_fabsf(v[j][e]));
-      }
     }
     for (int off = 1; off < C4 && off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if (C4 > 64) {   // C = 512: a tile is two waves (wave pairs 0/1 and 2/3 of the block)
@@ -877,18 +868,25 @@ __global__ __launch_bounds__(256) void wino4_in_h3_kernel(const float* __restric
       __syncthreads();
       mx = fmaxf(mx, wmax[par][wave ^ 1]);
     }
+    // every component is at most 49 max|d| (the rows of B^T sum to at most 7 in magnitude): with the scale taken from that
+    // bound a row of the transform is split and stored as soon as it is computed (no 36-plane live set: two waves per SIMD);
+    // the bound is loose by 2-3 bits, which only moves the point below which lo parts go subnormal (the MFMA honours them)
     float sc, uns;
-    split_scale_from_max(mx, sc, uns);
-    if (valid) {
-      if (c4 == 0) vs[t] = uns;
+    split_scale_from_max(49.f * mx, sc, uns);
+    if (valid && c4 == 0) vs[t] = uns;
+    float* vrow = V + t * C;
+    const long cstride = ntile_pad * C;
 #pragma unroll
-      for (int k = 0; k < 6; k++)
+    for (int k = 0; k < 6; k++) {
+      f32x4 v[6];
+      wino4_bt(u[k], v);
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-          uint2 hi, lo;
-          split4(u[k][j], sc, hi, lo);
-          store_split_pair(V + ((long)(k * 6 + j) * ntile_pad + t) * C, c4, hi, lo);
-        }
+      for (int j = 0; j < 6; j++) {
+        uint2 hi, lo;
+        split4(v[j], sc, hi, lo);
+        if (valid) store_split_pair(vrow, c4, hi, lo);
+        vrow += cstride;
+      }
     }
   }
 }
