@@ -3839,27 +3839,33 @@ void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld,
 }
 
 // ---------------------------------------------------------------------------
-// greedy CTC collapse, one thread per line
+// greedy CTC collapse, one wave per line: lane i looks at timestep base + i and its predecessor, the kept labels are
+// compacted with a ballot (position = kept labels before this lane).  (One thread per line walking its T steps took
+// 0.028 ms for 256 lines: 256 threads on the whole device.)
 // ---------------------------------------------------------------------------
-__global__ void ctc_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ tlen,
-                           int32_t* __restrict__ out, int32_t* __restrict__ len, int B, int T) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void ctc_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ tlen,
+                                                  int32_t* __restrict__ out, int32_t* __restrict__ len, int B, int T) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
   const int Ti = tlen ? tlen[b] : T;
   const int32_t* p = idx + (long)b * T;
   int32_t* o = out + (long)b * T;
-  int n = 0, prev = -1;
-  for (int i = 0; i < Ti; i++) {
-    const int k = p[i];
-    if (k != 0 && k != prev) o[n++] = k - 1;
-    prev = k;
+  int n = 0;
+  for (int base = 0; base < Ti; base += 64) {
+    const int t = base + lane;
+    const int k = t < Ti ? p[t] : 0;
+    const int kp = (t > 0 && t < Ti) ? p[t - 1] : -1;
+    const bool keep = t < Ti && k != 0 && k != kp;
+    const unsigned long long m = __ballot(keep);
+    if (keep) o[n + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = k - 1;
+    n += __builtin_popcountll(m);
   }
-  len[b] = n;
+  if (lane == 0) len[b] = n;
 }
 
 void launch_ctc(const int32_t* idx, const int32_t* tlen, int32_t* out, int32_t* len, int B, int T,
                 hipStream_t s) {
-  hipLaunchKernelGGL(ctc_kernel, dim3((B + 63) / 64), dim3(64), 0, s, idx, tlen, out, len, B, T);
+  hipLaunchKernelGGL(ctc_kernel, dim3((B + 3) / 4), dim3(256), 0, s, idx, tlen, out, len, B, T);
 }
 
 // ---------------------------------------------------------------------------
