@@ -730,7 +730,9 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       std::lock_guard<std::mutex> lk(h->split_mu);
       if (!h->split_ev) (void)hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming);
       if (h->split_ev) (void)hipStreamWaitEvent(s, h->split_ev, 0);
-      launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync, s);
+      static const bool sh3 = !(getenv("CRNN_SPLIT_H3") && atoi(getenv("CRNN_SPLIT_H3")) == 0);
+      if (sh3 && h->d_whh3[l]) launch_lstm_rec_split_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], d_sync, s);
+      else launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync, s);
       if (h->split_ev) (void)hipEventRecord(h->split_ev, s);
     }
     else if (h->d_whh3[l]) launch_lstm_rec_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], s);

@@ -3424,6 +3424,182 @@ void launch_lstm_rec_split(const float* xp, const float* whh_packed, float* rec,
                      tmo);
 }
 
+// ---------------------------------------------------------------------------
+// The hidden-split recurrence on the fp16 MFMA in the f16x3 form: lstm_rec_split_kernel's work split, exchange protocol
+// and time-out handling, lstm_rec_h3_kernel's arithmetic.  Workgroup `part` owns hidden units [64 part, 64 part + 64) of
+// all four gates, wave w the 16 units [.. + 16 w, ..); the wave's W_hh slice -- 4 gate tiles x 8 k-steps x (hi, lo)
+// fragments in pack_whh_h3's order, 64 KB, the same 256 registers as the fp32 slice -- stays resident, h lives in LDS
+// as split pairs (scale 2^14, lstm_rec_h3_kernel's layout), and a step is 96 v_mfma_f32_16x16x32_f16 per wave (0.7 us)
+// instead of 256 v_mfma_f32_16x16x4_f32 (3.5 us).  The chunks that arrive from the other parts are fp32 (the output
+// rows) and are split on the way into LDS.  Same MFMA sequence per accumulator and same gate math as
+// lstm_rec_h3_kernel: bit-identical to it (tests/test_hip_scale.py).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __restrict__ xp,
+                                                                const uint4* __restrict__ whh3, float* rec,
+                                                                const int32_t* __restrict__ tlen, int B, int T,
+                                                                float unscale, unsigned* tmo) {
+  __shared__ __attribute__((aligned(16))) unsigned char hs[2 * LB * HLS];
+  __shared__ int s_fail;
+  const int dir = blockIdx.y, grp = blockIdx.x >> 2, part = blockIdx.x & 3, b0 = grp * LB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
+  const int b = b0 + bl;
+  const int Ti = (b < B) ? (tlen ? tlen[b] : T) : 0;
+  int Tmax = 0;
+  for (int j = 0; j < LB; j++) {
+    const int bb = b0 + j;
+    const int tj = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
+    Tmax = tj > Tmax ? tj : Tmax;
+  }
+  for (int i = tid; i < 2 * LB * HLS / 4; i += 256) ((unsigned*)hs)[i] = 0u;
+  if (tid == 0) s_fail = 0;
+  // exchange loads: 3 other parts x 16 lines x 16 chunks of 4 units = 768 float4, 3 per thread
+  int xl_line[3], xl_unit[3], xl_T[3], xl_lds[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int e = i * 256 + tid;            // 0..767
+    const int op = e >> 8;                  // which of the 3 other parts
+    const int p2 = op + (op >= part ? 1 : 0);
+    xl_line[i] = (e >> 4) & 15;
+    xl_unit[i] = p2 * 64 + (e & 15) * 4;
+    const int bb = b0 + xl_line[i];
+    xl_T[i] = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
+    const int k = xl_unit[i];               // units k .. k + 3: block [k / 8 mod 4][k / 32], halves (k & 7) .. + 3
+    xl_lds[i] = xl_line[i] * HLS + ((k >> 3) & 3) * 256 + (k >> 5) * 32 + (k & 7) * 2;
+  }
+  const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, 0x7FFFFFFF, 0x00020000);
+  float c[4], h[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) { c[r] = 0.f; h[r] = 0.f; }
+  // the wave's weights: gate g, its 16 units, all 8 k-steps, (hi, lo) -- 64 uint4 per lane, resident
+  uint4 w[4][8][2];
+  {
+    const uint4* wp = whh3 + ((size_t)(dir * 4 + part) * 8 * 16 * 2) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        w[g][ks][0] = wp[(size_t)((ks * 16 + g * 4 + wave) * 2) * 64];
+        w[g][ks][1] = wp[(size_t)((ks * 16 + g * 4 + wave) * 2 + 1) * 64];
+      }
+  }
+  __syncthreads();
+  int cur = 0;
+  // where this lane's four units go in a line's split image
+  const int myu = part * 64 + wave * 16 + q * 4;
+  const int my_lds = bl * HLS + ((myu >> 3) & 3) * 256 + (myu >> 5) * 32 + (myu & 7) * 2;
+  for (int s = 0; s < Tmax; s++) {
+    const bool active = s < Ti;
+    const int t = active ? (dir ? (Ti - 1 - s) : s) : 0;
+    const size_t rowi = (size_t)(b < B ? b : 0) * T + t;
+    const float* xrow = xp + rowi * 2048 + dir * 1024 + part * 64 + wave * 16 + q * 4;
+    f32x4 xg[4], acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      xg[g] = active ? *(const f32x4*)(xrow + g * 256) : z;
+      acc[g] = z;
+    }
+    const unsigned char* hrow = hs + cur * LB * HLS + bl * HLS + q * 256;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      const f16x8r hh = *(const f16x8r*)(hrow + ks * 32), hl = *(const f16x8r*)(hrow + ks * 32 + 16);
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[g][ks][1]), hh, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[g][ks][0]), hl, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[g][ks][0]), hh, acc[g], 0, 0, 0);
+    }
+    f32x4 hv4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (active) {
+        const float ig = sigmoidf_(acc[0][r] * unscale + xg[0][r]);
+        const float fg = sigmoidf_(acc[1][r] * unscale + xg[1][r]);
+        const float gg = tanhf_(acc[2][r] * unscale + xg[2][r]);
+        const float og = sigmoidf_(acc[3][r] * unscale + xg[3][r]);
+        c[r] = fg * c[r] + ig * gg;
+        h[r] = og * tanhf_(c[r]);
+      }
+      hv4[r] = h[r];
+    }
+    {
+      uint2 hi, lo;
+      split4(hv4, 16384.f, hi, lo);
+      unsigned char* d = hs + (cur ^ 1) * LB * HLS + my_lds;
+      *(uint2*)d = hi;
+      *(uint2*)(d + 16) = lo;
+    }
+    if (active)   // write-through store: the output row AND the hand-off to the other three workgroups
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv4), rec_rsrc,
+                                             (unsigned)((rowi * 512 + dir * 256 + myu) * 4), 0, 16);
+    // the other parts' h of this step: lstm_rec_split_kernel's protocol (the fill pattern is the arrival flag)
+    {
+      i32x4 v[3];
+      bool act[3], pend[3];
+      unsigned ro[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int Tl = xl_T[i], ln = xl_line[i];
+        act[i] = s < Tl;
+        const int tl = dir ? (Tl - 1 - s) : s;
+        ro[i] = (unsigned)((((size_t)(b0 + ln) * T + tl) * 512 + dir * 256 + xl_unit[i]) * 4);
+        pend[i] = act[i];
+      }
+      unsigned spins = 0;
+      bool fail = false;
+      while (pend[0] || pend[1] || pend[2]) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+          if (pend[i]) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, ro[i], 0, 16);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+          if (pend[i]) pend[i] = v[i][0] == -1 || v[i][1] == -1 || v[i][2] == -1 || v[i][3] == -1;
+        if (++spins > SPLIT_MAX_SPINS) { fail = true; break; }
+        if ((spins & 255u) == 0 &&
+            __hip_atomic_load((gu32_t*)tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = true; break; }
+      }
+      if (fail) {
+        __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_fail = 1;
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        unsigned char* dst = hs + (cur ^ 1) * LB * HLS + xl_lds[i];
+        const unsigned char* old = hs + cur * LB * HLS + xl_lds[i];
+        uint2 hi, lo;
+        if (act[i]) split4(__builtin_bit_cast(f32x4, v[i]), 16384.f, hi, lo);
+        else { hi = *(const uint2*)old; lo = *(const uint2*)(old + 16); }
+        *(uint2*)dst = hi;
+        *(uint2*)(dst + 16) = lo;
+      }
+    }
+    __syncthreads();
+    if (s_fail) return;     // uniform: everybody leaves; the host repeats the batch with the one-workgroup kernel
+    __syncthreads();
+    cur ^= 1;
+  }
+  // padding rows (t >= T_i) of this workgroup's lines, direction and 64 units: zero instead of the fill pattern
+  for (int ln = 0; ln < LB; ln++) {
+    const int bb = b0 + ln;
+    if (bb >= B) break;
+    const int Tl = tlen ? tlen[bb] : T;
+    for (int r = Tl * 16 + tid; r < T * 16; r += 256)
+      *(f32x4*)(rec + ((size_t)bb * T + (r >> 4)) * 512 + dir * 256 + part * 64 + (r & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+void launch_lstm_rec_split_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T,
+                              float unscale, unsigned* tmo, hipStream_t s) {
+  const int groups = (B + LB - 1) / LB;
+  (void)hipMemsetAsync(rec, 0xFF, (size_t)B * T * 512 * sizeof(float), s);   // the arrival flags (see launch_lstm_rec_split)
+  hipLaunchKernelGGL(lstm_rec_split_h3_kernel, dim3(groups * 4, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen, B,
+                     T, unscale, tmo);
+}
+
 void launch_lstm_rec(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,
                      int T, hipStream_t s) {
   hipLaunchKernelGGL(lstm_rec_kernel, dim3((B + LB - 1) / LB, 2), dim3(256), 0, s, xp, whh_packed, rec,

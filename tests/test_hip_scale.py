@@ -234,15 +234,18 @@ def test_pages_from_two_threads_use_their_own_lanes(golden, zh3):
 
 
 @pytest.mark.gpu
-def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh):
-    """Small batches use the four-workgroups-per-group recurrence (lstm_rec_split_kernel) in the synchronous
-    host paths; it must reproduce the one-workgroup kernel bit for bit: same logits for n = 1, 17, 48 and 200 lines
-    of different widths (lines ending at different steps exercise the keep-old-h path of the exchange)."""
+@pytest.mark.parametrize("rec_h3", ["0", "1"])
+def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh, rec_h3):
+    """Small batches use the four-workgroups-per-group recurrence (lstm_rec_split_kernel / lstm_rec_split_h3_kernel) in
+    the synchronous host paths; it must reproduce the one-workgroup kernel of the same arithmetic bit for bit: same logits
+    for n = 1, 17, 48 and 200 lines of different widths (lines ending at different steps exercise the keep-old-h path of
+    the exchange).  rec_h3 = "0": both on the f32 MFMA; "1": both in the f16x3 form (the two forms are equally accurate
+    but not bit-identical to each other)."""
     from ocr_amd.crnn.network_hip import CRNN
     G, M = golden
     old = os.environ.get("CRNN_LSTM_SPLIT")
     old_h3 = os.environ.get("CRNN_REC_H3")
-    os.environ["CRNN_REC_H3"] = "0"      # both on the f32 MFMA: the f16x3 recurrence is equally accurate but not bit-identical
+    os.environ["CRNN_REC_H3"] = rec_h3
     try:
         os.environ["CRNN_LSTM_SPLIT"] = "0"
         ref = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1)

@@ -55,6 +55,7 @@ VARIANTS = [
     ({"CRNN_LIN_GEMM": "0"}, 1),                              # input projections / classifier on conv_gemm_kernel
     ({"CRNN_F16X3": "0"}, 1),                                 # Winograd GEMMs on the f32 MFMA instead of the f16x3 form
     ({"CRNN_F16X3": "0"}, 4),
+    ({"CRNN_SPLIT_H3": "0"}, 1),                              # hidden-split recurrence on the f32 MFMA
     ({"CRNN_GEMM16_DMA": "0"}, 1),                            # classifier pre-filter GEMM on conv_gemm_bf16_kernel
     ({"CRNN_GEMM16_DMA": "0", "CRNN_CLS_F16": "0"}, 2),
     ({"CRNN_CONV0_FUSED": "0"}, 1),                           # conv0 + pool0 and conv1's input transform as two kernels
@@ -74,7 +75,7 @@ VARIANTS = [
 def test_variant_strings_match_reference_goldens(env, lanes, golden):
     _, M = golden
     e = dict(os.environ)
-    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA", "CRNN_WINOGRAD_F4", "CRNN_WINO4_SHAPE", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_LW", "CRNN_WINO4_POOL21", "CRNN_WINO6", "CRNN_CLS_FILTER", "CRNN_F16X3", "CRNN_REC_H3", "CRNN_LSTM_SPLIT", "CRNN_H3_LW", "CRNN_CLS_F16", "CRNN_WINO4_FUSE", "CRNN_CONV0_FUSED", "CRNN_GEMM16_DMA"):
+    for k in ("CRNN_WINOGRAD", "CRNN_WINO_FUSED", "CRNN_WINO_DMA", "CRNN_WINOGRAD_F4", "CRNN_WINO4_SHAPE", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_LW", "CRNN_WINO4_POOL21", "CRNN_WINO6", "CRNN_CLS_FILTER", "CRNN_F16X3", "CRNN_REC_H3", "CRNN_LSTM_SPLIT", "CRNN_H3_LW", "CRNN_CLS_F16", "CRNN_WINO4_FUSE", "CRNN_CONV0_FUSED", "CRNN_GEMM16_DMA", "CRNN_SPLIT_H3"):
         e.pop(k, None)
     e.update(env)
     code = CHILD % (ROOT, os.path.join(ROOT, "tests", "golden", "crnn_golden.npz"),
