@@ -65,8 +65,9 @@ typedef struct {
   int32_t lstm;       /* lstmFlag */
   int32_t device;     /* HIP device ordinal (config.GPUID) */
   int32_t lanes;      /* independent (stream, workspace) lanes crnn_forward_device rotates over; 0 -> 1, max 8 */
-  int32_t precision;  /* CRNN_FP32 (exact fp32 MFMA; the parity path) or CRNN_BF16 (bf16 MFMA inputs, fp32
-                         accumulate; reports character agreement, not held to the 1e-3 logit bound) */
+  int32_t precision;  /* CRNN_FP32 (the parity path: fp32-accurate arithmetic -- GEMM operands as (hi, lo) fp16 pairs on
+                         the fp16 MFMA with fp32 accumulation, or the f32 MFMA with CRNN_F16X3=0) or CRNN_BF16 (bf16 MFMA
+                         inputs, fp32 accumulate; reports character agreement, not held to the 1e-3 logit bound) */
   int32_t reserved;
 } crnn_config;
 
