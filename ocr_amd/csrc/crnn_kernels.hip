@@ -2750,7 +2750,9 @@ __global__ __launch_bounds__(256, 2) void conv0_win4_h3_kernel(const float* __re
   const int W1 = W >> 1, ntx = (W1 + 3) >> 2, ngrp = (ntx + C0_TXB - 1) / C0_TXB;
   const int cg = threadIdx.x & 15, sub = threadIdx.x >> 4;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  for (int blk = blockIdx.x; blk < B * ngrp; blk += gridDim.x) {
+  {   // one block per (line, group of 4 tile columns): a grid-stride loop here makes the compiler hoist the per-thread
+      // index arithmetic of all three phases out of it and spill (scratch memory; none is used now)
+    const int blk = blockIdx.x;
     const int b = blk / ngrp, grp = blk - b * ngrp;
     const int x1base = 4 * C0_TXB * grp - 1;
     const int wlim = w1valid ? (w1valid[b] < W1 ? w1valid[b] : W1) : W1;
@@ -2835,7 +2837,7 @@ __global__ __launch_bounds__(256, 2) void conv0_win4_h3_kernel(const float* __re
         wino4_bt(d, c);
 #pragma unroll
         for (int k = 0; k < 6; k++) u[k][j] = c[k];
-        if (j & 1) __builtin_amdgcn_sched_barrier(0);   // two columns of loads in flight, not all six (registers)
+        __builtin_amdgcn_sched_barrier(0);   // one column of loads in flight, not all six (registers: no spills, no scratch)
       }
 #pragma unroll
       for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
@@ -2865,8 +2867,7 @@ __global__ __launch_bounds__(256, 2) void conv0_win4_h3_kernel(const float* __re
 void launch_conv0_win4(const float* in, const float* w9x64, const float* bias, float* V, float* vs,
                        const int32_t* w1valid, int B, int W, int act, hipStream_t s) {
   const int W1 = W >> 1, ntx = (W1 + 3) >> 2, ngrp = (ntx + C0_TXB - 1) / C0_TXB;
-  long blocks = (long)B * ngrp;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const long blocks = (long)B * ngrp;
   hipLaunchKernelGGL(conv0_win4_h3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, w9x64, bias, V, vs, w1valid, B, W,
                      act, wino4_pad(wino4_tiles(B, 16, W1)));
 }
