@@ -2042,7 +2042,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
   // of an XCD stride through their rectangle row-major -- the rectangle's slice of W stays in that XCD's L2
   // and an A tile is fetched once per column group instead of once per XCD and n-tile.
   int nb, ne, gw, mb, me, first, stride, my_units;
-  if (p.gn > 0 && G == 256) {
+  if (p.gn > 0) {   // (set by the launcher only for a full launch: G a multiple of 8, every XCD's rectangle >= G / 8 units)
     const int x = blockIdx.x & 7, gm = 8 / p.gn, cg = x % p.gn, rg = x / p.gn;
     nb = cg * ntn / p.gn; ne = (cg + 1) * ntn / p.gn;
     mb = rg * ntm / gm; me = (rg + 1) * ntm / gm;
@@ -2263,7 +2263,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_h3_kernel(const ConvGemm p) {
   // of an XCD stride through their rectangle row-major -- the rectangle's slice of W stays in that XCD's L2
   // and an A tile is fetched once per column group instead of once per XCD and n-tile.
   int nb, ne, gw, mb, me, first, stride, my_units;
-  if (p.gn > 0 && G == 256) {
+  if (p.gn > 0) {   // (set by the launcher only for a full launch: G a multiple of 8, every XCD's rectangle >= G / 8 units)
     const int x = blockIdx.x & 7, gm = 8 / p.gn, cg = x % p.gn, rg = x / p.gn;
     nb = cg * ntn / p.gn; ne = (cg + 1) * ntn / p.gn;
     mb = rg * ntm / gm; me = (rg + 1) * ntm / gm;
@@ -2459,10 +2459,10 @@ void launch_lin_gemm(const ConvGemm& p0, hipStream_t s) {
   // provided every XCD's rectangle still has at least one unit per block
   p.gn = 0;
   static const int force = getenv("CRNN_LIN_GN") ? atoi(getenv("CRNN_LIN_GN")) : -1;
-  if (g == 256) {
+  if (g == persistent_blocks() && g % 8 == 0) {
     for (int gn = 1; gn <= 8; gn *= 2) {
       const double slice = (double)p.N * p.K * 4 / gn;
-      if ((slice <= 3.0e6 || gn == 8) && ntn >= gn && ntm >= 8 / gn && (ntn / gn) * (ntm / (8 / gn)) >= 32) { p.gn = gn; break; }
+      if ((slice <= 3.0e6 || gn == 8) && ntn >= gn && ntm >= 8 / gn && (ntn / gn) * (ntm / (8 / gn)) >= g / 8) { p.gn = gn; break; }
     }
     if (force >= 0) p.gn = force;
   }
