@@ -602,8 +602,13 @@ __global__ __launch_bounds__(256) void lstm_rec_bf16_kernel(const float* __restr
   for (int u = 0; u < 4; u++)
 #pragma unroll
     for (int r = 0; r < 4; r++) { c[u][r] = 0.f; h[u][r] = 0.f; }
-  // packed: [dir][wave][kstep 8][tile 16][lane 64] x 8 bf16
+  // packed: [dir][wave][kstep 8][tile 16][lane 64] x 8 bf16; streamed through two register sets of 8 tiles, half a
+  // k-step ahead of the MFMAs (as lstm_rec_h3_kernel: with the loads left to the compiler a step took 11 us, as long as
+  // the f16x3 form with twice the bytes)
   const bf16x8* wp = (const bf16x8*)whhp + ((size_t)(dir * 4 + wave) * 8 * 16) * 64 + lane;
+  bf16x8 wa[8], wb[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) wa[i] = wp[(size_t)i * 64];
   __syncthreads();
   int cur = 0;
   for (int s = 0; s < Tmax; s++) {
@@ -625,15 +630,20 @@ __global__ __launch_bounds__(256) void lstm_rec_bf16_kernel(const float* __restr
 #pragma unroll
       for (int u = 0; u < 4; u++) acc[g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     const __bf16* hrow = hs + cur * LB * HSB + bl * HSB + 8 * q;
-#pragma unroll 2
+#pragma unroll 1
     for (int ks = 0; ks < 8; ks++) {
       const bf16x8 hv = *(const bf16x8*)(hrow + ks * 32);
 #pragma unroll
-      for (int tile = 0; tile < 16; tile++) {
-        const bf16x8 av = wp[(size_t)(ks * 16 + tile) * 64];
-        acc[tile >> 2][tile & 3] =
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, hv, acc[tile >> 2][tile & 3], 0, 0, 0);
-      }
+      for (int i = 0; i < 8; i++) wb[i] = wp[(size_t)(ks * 16 + 8 + i) * 64];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        acc[i >> 2][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], hv, acc[i >> 2][i & 3], 0, 0, 0);
+      const int kn = (ks + 1) & 7;   // the last refill wraps to k-step 0 of the NEXT step: it lands under the gate math
+#pragma unroll
+      for (int i = 0; i < 8; i++) wa[i] = wp[(size_t)(kn * 16 + i) * 64];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        acc[2 + (i >> 2)][i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], hv, acc[2 + (i >> 2)][i & 3], 0, 0, 0);
     }
     __bf16* hn = hs + (cur ^ 1) * LB * HSB + bl * HSB + wave * 64 + q * 4;
 #pragma unroll
