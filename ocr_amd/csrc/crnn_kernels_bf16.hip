@@ -24,7 +24,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BN = 128, BKH = 64, LDB = 144;  // LDB: LDS row stride in bytes
 
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
-template <int OUT_BF16>   // 0: fp32 output, 1: bf16 output, 2: fp16 operands and output (same bytes, v_mfma_f32_32x32x16_f16)
+// SW (bf16 output, N % 128 == 0, ldc % 8 == 0, no arg-max): the W fragment is the first MFMA operand, so a lane ends with 4
+// consecutive columns of one row, and the block's output goes through the (by then free) LDS tile buffer as whole
+// 128-byte lines of C instead of 2-byte pieces of 32 different rows.
+template <int OUT_BF16, bool SW = false>   // 0: fp32 output, 1: bf16 output, 2: fp16 operands and output (same bytes, v_mfma_f32_32x32x16_f16)
 __global__ __launch_bounds__(256, 3) void conv_gemm_bf16_kernel(const ConvGemm p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,6 +118,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16_kernel(const ConvGemm p
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha0, hb1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1, hb0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1, hb1, acc[1][1], 0, 0, 0);
+      } else if (SW) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
       } else {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
@@ -141,12 +149,56 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16_kernel(const ConvGemm p
     if (!p.C) return;
   }
 
+  if (SW) {
+    // acc[i][j][4 g + e] = C[m0 + wm 64 + i 32 + (lane & 31)][n0 + wn 64 + j 32 + 8 g + 4 (lane >> 5) + e]
+    __syncthreads();   // every wave is done with the operand tiles: the buffer becomes four 64-row output tiles
+    unsigned char* wt = smem + wave * (64 * 144);
+    const int act = p.act, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+      bool keep = true;
+      if (p.wvalid) {
+        const int mm = m < p.M ? m : p.M - 1;
+        const int b = mm / hw, x = (mm - b * hw) % p.Wout;
+        keep = x < p.wvalid[b];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int nl = j * 32 + 8 * g + 4 * h;
+          const f32x4 bs = *(const f32x4*)(p.bias + n0 + wn * 64 + nl);
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float v = acc[i][j][4 * g + e] + bs[e];
+            const float neg = act == 2 ? 0.2f * v : (act == 1 ? 0.f : v);
+            v = v > 0.f ? v : neg;
+            o[e] = (__bf16)(keep ? v : 0.f);
+          }
+          *(bf16x4*)(wt + (i * 32 + (lane & 31)) * 144 + nl * 2) = o;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int row = it * 8 + (lane >> 3);
+      const i32x4 v = *(const i32x4*)(wt + row * 144 + (lane & 7) * 16);
+      const int m = m0 + wm * 64 + row;
+      if (m < p.M) *(i32x4*)((__bf16*)p.C + (long)m * p.ldc + n0 + wn * 64 + (lane & 7) * 8) = v;
+    }
+    return;
+  }
   store_epilogue<OUT_BF16>(acc, p, p.C, m0, n0, wm, wn, lane);
 }
 
 void launch_conv_gemm_bf16(const ConvGemm& p, int out_mode, hipStream_t s) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   if (out_mode == 2) hipLaunchKernelGGL(conv_gemm_bf16_kernel<2>, dim3(ntm * ntn), dim3(256), 0, s, p);
+  else if (out_mode && !p.pmax && p.N % 128 == 0 && p.ldc % 8 == 0 && p.nbatch <= 1)
+    hipLaunchKernelGGL((conv_gemm_bf16_kernel<1, true>), dim3(ntm * ntn), dim3(256), 0, s, p);   // line-wide stores through LDS
   else if (out_mode) hipLaunchKernelGGL(conv_gemm_bf16_kernel<1>, dim3(ntm * ntn), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(conv_gemm_bf16_kernel<0>, dim3(ntm * ntn), dim3(256), 0, s, p);
 }
