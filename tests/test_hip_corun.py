@@ -1,0 +1,33 @@
+"""Kernels of different streams sharing a CU (GPU): the product kernels must give the same bits beside an MFMA kernel.
+
+Round 2 found that packed-fp32 instructions with op_sel return a wrong low result now and then while a wave of another
+kernel executes 16-bit MFMAs on the same CU (ocr_amd/csrc/crnn_kernels_nopk.hip has the measurements).  The tests:
+tools/corun_test (built by ocr_amd/csrc/Makefile) runs conv0_win4_h3_kernel beside the kernels that exposed it, and the
+built library must not contain such an instruction anywhere (tools/check_isa.py; runs without a GPU).
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "corun_test")
+LIB = os.path.join(ROOT, "ocr_amd", "libcrnn_hip.so")
+
+
+def test_library_has_no_packed_fp32_with_op_sel():
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py"), LIB], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aggressor", [1, 11, 14])   # the classifier filter GEMM of one crop; bf16 / fp16 MFMA on every CU
+def test_conv0_win4_beside_mfma_kernels(aggressor):
+    assert os.path.exists(TOOL), "tools/corun_test missing: make -C ocr_amd/csrc"
+    r = subprocess.run([TOOL, str(aggressor), "3000"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0 and " 0 of 3000 iterations differ" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Build check: no packed-fp32 instruction with op_sel in the device code of a library.
+
+v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel (the LOW result taking the HIGH dword of a source) were measured on
+MI355X to give a wrong low result now and then while a wave of another kernel runs 16-bit MFMAs on the same CU
+(tools/corun_test.hip).  The compiler chooses those forms by itself, so the Makefile runs this over the built
+library: every gfx950 code object is extracted and disassembled, and any such instruction fails the build (mark the kernel
+CRNN_NO_PK_F32, crnn_kernels.h).
+
+    python tools/check_isa.py ocr_amd/libcrnn_hip.so
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+PK = re.compile(r"\bv_pk_(fma|mul|add)_f32\b")
+SEL = re.compile(r"op_sel:\[([01,]+)\]")
+
+
+def main():
+    lib = sys.argv[1]
+    bad = []
+    n_pk = 0
+    with tempfile.TemporaryDirectory() as td:
+        tmp = os.path.join(td, os.path.basename(lib))
+        shutil.copy(lib, tmp)
+        subprocess.run([LLVM + "/llvm-objdump", "--offloading", tmp], check=True, stdout=subprocess.DEVNULL)
+        cos = [f for f in os.listdir(td) if "amdgcn" in f]
+        if not cos:
+            print("check_isa: no device code object found in", lib)
+            return 1
+        for co in sorted(cos):
+            out = subprocess.run([LLVM + "/llvm-objdump", "-d", os.path.join(td, co)], check=True, capture_output=True,
+                                 text=True).stdout
+            fn = "?"
+            for line in out.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+                if m:
+                    fn = m.group(1)
+                    continue
+                if PK.search(line):
+                    n_pk += 1
+                    s = SEL.search(line)
+                    if s and "1" in s.group(1):
+                        bad.append((fn, line.strip().split("//")[0].strip()))
+    if bad:
+        kernels = sorted(set(b[0] for b in bad))
+        print("check_isa: %d packed-fp32 instructions with op_sel in %d kernels (mark them CRNN_NO_PK_F32):" % (len(bad), len(kernels)))
+        for k in kernels:
+            ex = next(b[1] for b in bad if b[0] == k)
+            print("  %s   e.g. %s" % (k, ex))
+        return 1
+    print("check_isa: ok (%d packed-fp32 instructions, none with op_sel)" % n_pk)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,83 @@
+"""Stress the shared-handle host path: K threads call CRNN.ocr on the invoice crops of the goldens for many rounds
+and every string is compared with the reference's golden string.  Prints one JSON line; exit status 1 on any mismatch.
+(This is what found the packed-fp32 / MFMA co-run problem described in ocr_amd/csrc/crnn_kernels_nopk.hip: 10-20
+wrong strings in 25 000 calls from two threads before the fix, none after.)
+
+    python tools/stress_threads.py [--threads 2] [--rounds 500] [--lanes 3]
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--threads", type=int, default=2)
+    ap.add_argument("--rounds", type=int, default=500)
+    ap.add_argument("--lanes", type=int, default=3)
+    ap.add_argument("--own-handle", type=int, default=0, help="1: every thread has a model object of its own")
+    ap.add_argument("--shuffle", type=int, default=0, help="each thread visits its crops in a random order (seed)")
+    args = ap.parse_args()
+    from ocr_amd.crnn import keys
+    from ocr_amd.crnn.network_hip import CRNN
+    from ocr_amd.crnn.synth import synth_state_dict
+    G = np.load(os.path.join(ROOT, "tests", "golden", "crnn_golden.npz"))
+    with open(os.path.join(ROOT, "tests", "golden", "crnn_golden.json"), encoding="utf-8") as f:
+        M = json.load(f)
+    crops = [G["inv/%s/bgr" % it["name"]] for it in M["invoice"]]
+    want = [it["zh"] for it in M["invoice"]]
+    sd = synth_state_dict(5530, seed=0)
+    models = []
+    for _ in range(args.threads if args.own_handle else 1):
+        mm = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, lanes=args.lanes)
+        mm.load_state_dict(sd)
+        models.append(mm)
+    m = models[0]
+    bad = []
+    calls = [0] * args.threads
+
+    def work(k):
+        rng = np.random.default_rng(args.shuffle + k)
+        m = models[k % len(models)]
+        prev = -1
+        for r in range(args.rounds):
+            idx = list(range(k, len(crops), args.threads))
+            if args.shuffle:
+                idx = [int(j) for j in rng.permutation(len(crops))]
+            for i in idx:
+                got = m.ocr(crops[i])
+                calls[k] += 1
+                if got != want[i]:
+                    bad.append({"thread": k, "round": r, "crop": i, "prev": prev, "w": int(crops[i].shape[1]),
+                                "got": got, "want": want[i]})
+                    if len(bad) > 20:
+                        return
+                prev = i
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(args.threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    out = {"threads": args.threads, "lanes": args.lanes, "calls": sum(calls), "mismatches": len(bad),
+           "seconds": round(time.time() - t0, 2), "first": bad[:3]}
+    if hasattr(m, "split_timeouts"):
+        try:
+            out["split_timeouts"] = int(m.split_timeouts())
+        except Exception:  # noqa: BLE001
+            pass
+    print(json.dumps(out, ensure_ascii=False))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
