@@ -63,6 +63,39 @@ def test_batch256_matches_golden_lines_anywhere_in_the_batch(golden, zh3):
         assert texts[i] == strLabelConverter(raw[i], keys.alphabetChinese)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pipelined_batches_equal_a_serial_run(synth_zh, precision):
+    """bench.py's mode: batches queued back to back on four lanes, so kernels of different batches share CUs.  Every
+    batch must come out bit-identical to a batch run alone (kernels must not disturb each other: the packed-fp32 / MFMA
+    co-run problem of crnn_kernels_nopk.hip showed as a few wrong pixels in one batch of many)."""
+    import torch
+    from ocr_amd.crnn.network_hip import CRNN
+    m = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, lanes=4, precision=precision)
+    m.load_state_dict(synth_zh)
+    dev = torch.device("cuda", 0)
+    n, w, T, NB = 256, 280, 71, 48
+    rs = np.random.RandomState(11)
+    inputs = [torch.from_numpy(rs.randint(0, 256, size=(n, 32, w)).astype(np.uint8)).to(dev) for _ in range(3)]
+    ref = []
+    for d in inputs:     # alone, synchronous
+        raw = torch.zeros((n, T), dtype=torch.int32, device=dev)
+        lab = torch.zeros((n, T), dtype=torch.int32, device=dev)
+        ln = torch.zeros((n,), dtype=torch.int32, device=dev)
+        m.forward_device(d.data_ptr(), n, w, lab.data_ptr(), ln.data_ptr(), d_raw_ptr=raw.data_ptr(), sync=True)
+        ref.append((raw.cpu().numpy(), lab.cpu().numpy(), ln.cpu().numpy()))
+    outs = [(torch.zeros((n, T), dtype=torch.int32, device=dev), torch.zeros((n, T), dtype=torch.int32, device=dev),
+             torch.zeros((n,), dtype=torch.int32, device=dev)) for _ in range(NB)]
+    torch.cuda.synchronize()
+    for k, (raw, lab, ln) in enumerate(outs):     # queued without waiting
+        m.forward_device(inputs[k % 3].data_ptr(), n, w, lab.data_ptr(), ln.data_ptr(), d_raw_ptr=raw.data_ptr())
+    m.synchronize()
+    for k, (raw, lab, ln) in enumerate(outs):
+        r = ref[k % 3]
+        bad = int((raw.cpu().numpy() != r[0]).sum())
+        assert bad == 0, "batch %d: %d arg-max indices differ from the serial run" % (k, bad)
+        assert np.array_equal(lab.cpu().numpy(), r[1]) and np.array_equal(ln.cpu().numpy(), r[2])
+
+
 def test_masked_batch_equals_exact_width_batches(zh3):
     """Config 3 shape: lines of different widths in ONE padded device batch (per-line masks) decode
     exactly like the same lines run in batches of their own width."""
@@ -92,9 +125,9 @@ def test_two_threads_share_one_handle(golden, zh3):
 
     def work(k):
         try:
-            # 150 rounds: a wrong string in 1 of ~1500 calls is what the packed-fp32 / MFMA co-run problem looked like
+            # 400 rounds (6800 calls): a wrong string in 1 of ~1500 calls is what the packed-fp32 / MFMA co-run problem looked like
             # from here (crnn_kernels_nopk.hip; tools/stress_threads.py is the long form of this test)
-            for r in range(150):
+            for r in range(400):
                 for c, w in list(zip(crops, want))[k::2]:
                     got = zh3.ocr(c)
                     assert got == w, "thread %d round %d: %r != %r" % (k, r, got, w)

@@ -4,8 +4,8 @@
 v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel (the LOW result taking the HIGH dword of a source) were measured on
 MI355X to give a wrong low result now and then while a wave of another kernel runs 16-bit MFMAs on the same CU
 (tools/corun_test.hip).  The compiler chooses those forms by itself, so the Makefile runs this over the built
-library: every gfx950 code object is extracted and disassembled, and any such instruction fails the build (mark the kernel
-CRNN_NO_PK_F32, crnn_kernels.h).
+library: every gfx950 code object is extracted and disassembled, and any such instruction fails the build (move the kernel to
+crnn_kernels_nopk.hip, which is compiled without packed fp32).
 
     python tools/check_isa.py ocr_amd/libcrnn_hip.so
 """
@@ -49,7 +49,7 @@ def main():
                         bad.append((fn, line.strip().split("//")[0].strip()))
     if bad:
         kernels = sorted(set(b[0] for b in bad))
-        print("check_isa: %d packed-fp32 instructions with op_sel in %d kernels (mark them CRNN_NO_PK_F32):" % (len(bad), len(kernels)))
+        print("check_isa: %d packed-fp32 instructions with op_sel in %d kernels (move them to crnn_kernels_nopk.hip):" % (len(bad), len(kernels)))
         for k in kernels:
             ex = next(b[1] for b in bad if b[0] == k)
             print("  %s   e.g. %s" % (k, ex))
