@@ -45,7 +45,7 @@ if not os.environ.get("CRNN_KEEP_HW_QUEUES") and int(os.environ.get("GPU_MAX_HW_
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH, WIDTH, NCLASS = 256, 280, 5530
+BATCH, WIDTH, NCLASS = int(os.environ.get("CRNN_BENCH_BATCH", "256")), 280, 5530   # the env override is for experiments only (configs[1] is 256)
 FLOP_PER_LINE = 4283.46e6          # 2*MACs per 32x280 line, nclass 5530
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32 MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA peak
