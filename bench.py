@@ -35,15 +35,16 @@ import time
 
 import numpy as np
 
-# The lanes are HIP streams: the runtime needs enough hardware queues for them (GPU_MAX_HW_QUEUES, read when HIP
-# initialises; its default of 4 makes four lanes slower than three).  A deployment exports the variable itself
-# (INTEGRATION.md); this script sets it when it is unset, before anything initialises HIP, and the value in effect is
-# recorded in the JSON line (config.gpu_max_hw_queues).  See ocr_amd/crnn/_capi.py _more_hw_queues.
-if not os.environ.get("CRNN_KEEP_HW_QUEUES") and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# The lanes are HIP streams: the runtime needs enough hardware queues for them (GPU_MAX_HW_QUEUES, read when HIP
+# initialises; its default of 4 makes four lanes slower than three).  A deployment exports the variable itself
+# (INTEGRATION.md); importing the binding raises it to 8 when it is unset and HIP is not up yet (under a profiler that
+# has initialised HIP already it records the 4 in effect instead), and the value in effect goes into the JSON line
+# (config.gpu_max_hw_queues).  See ocr_amd/crnn/_capi.py _more_hw_queues.
+from ocr_amd.crnn import _capi  # noqa: E402,F401  (before torch: must precede HIP initialisation)
+
 
 BATCH, WIDTH, NCLASS = int(os.environ.get("CRNN_BENCH_BATCH", "256")), 280, 5530   # the env override is for experiments only (configs[1] is 256)
 FLOP_PER_LINE = 4283.46e6          # 2*MACs per 32x280 line, nclass 5530
@@ -172,6 +173,13 @@ def lines_job(args, model, dev, rank, world, dist):
     assert total == N, (total, N)
     if rank == 0:
         chars = sum(len(t) for p in parts for t in p.values())
+        # digest of the gathered strings in line order: the same job must give the same digest on any number of ranks
+        import hashlib
+        allt = {}
+        for p in parts:
+            allt.update(p)
+        assert sorted(allt) == list(range(N)), "gathered line indices are not 0..N-1 exactly once"
+        digest = hashlib.sha256("\n".join(allt[i] for i in range(N)).encode("utf-8")).hexdigest()
         steps = max(1, (N + BATCH - 1) // BATCH)
         out = {"metric": "text-lines/sec at 32x280 crops (CRNN ocr-lstm head, 5530 classes)",
                "value": round(N / elapsed, 1), "unit": "text-lines/s", "n_gpus": world, "steps": steps,
@@ -184,10 +192,45 @@ def lines_job(args, model, dev, rank, world, dist):
                           "lines": N, "batch": BATCH, "width": WIDTH, "nclass": NCLASS, "lanes_per_gpu": NL,
                           "buckets_rank0": nb, "sharding": "independent lines, one replica per GPU, no collective",
                           "gpu_max_hw_queues": _hw_queues()},
-               "elapsed_s": round(elapsed, 3), "decoded_chars": chars}
+               "elapsed_s": round(elapsed, 3), "decoded_chars": chars, "strings_sha256": digest,
+               "lines_per_rank": [len(p) for p in parts]}
         print(json.dumps(out, ensure_ascii=False))
     if world > 1:
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher: start N child processes of this script, one per GPU (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would set them), wait for all of
+    them and return the first non-zero exit code.  The children inherit stdout, so rank 0's JSON line is this
+    process's output.  The parent never initialises HIP and never execs."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            c = p.wait()
+            if c and not rc:
+                rc = c
+                for q in procs:          # one rank failed: the others would wait at a barrier for ever
+                    if q.poll() is None:
+                        q.terminate()
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        rc = 130
+    return rc
 
 
 def _hw_queues():
@@ -212,6 +255,11 @@ def main():
                     help="one batch at a time (for rocprofv3 --kernel-trace --stats: per-kernel durations that are "
                          "not stretched by the other lanes, with the tile shapes the pipelined run uses)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called without a launcher: be the launcher.  Nothing in this process has touched HIP yet (torch is not even
+        # imported), the ranks are fresh child processes, and rank 0's JSON line passes through on its stdout.
+        raise SystemExit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

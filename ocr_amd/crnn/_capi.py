@@ -51,16 +51,28 @@ def _more_hw_queues():
         cur = 0
     if os.environ.get("CRNN_KEEP_HW_QUEUES") or cur >= 8:
         return
-    import sys
-    torch = sys.modules.get("torch")
-    try:
-        hip_up = bool(torch is not None and torch.cuda.is_initialized())
-    except Exception:  # noqa: BLE001
-        hip_up = False
-    if hip_up:
+    if _hip_already_up():
         os.environ.setdefault("CRNN_EFFECTIVE_HW_QUEUES", str(cur or 4))
     else:
         os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
+
+def _hip_already_up():
+    """True when the HIP runtime of this process has (or may have) read GPU_MAX_HW_QUEUES already: torch has
+    initialised its device context, or a profiler tool library is loaded -- under `rocprofv3 --pmc -- python3 ...` the
+    tool brings HIP up before Python starts, so a later change of the variable would be recorded but not in effect."""
+    import sys
+    torch = sys.modules.get("torch")
+    try:
+        if torch is not None and torch.cuda.is_initialized():
+            return True
+    except Exception:  # noqa: BLE001
+        pass
+    if any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD")):
+        return True
+    if "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return True
+    return False
 
 
 def effective_hw_queues():

@@ -26,7 +26,7 @@
  *     Image.resize(BILINEAR) (libImaging/Resample.c: precompute_coeffs,
  *     normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc,
  *     ImagingResampleInner).  Checked bit-exact against the installed Pillow
- *     in tests/test_oracle_preprocess.py.
+ *     in tests/test_oracle_golden.py.
  *   - PyTorch nn.Conv2d / BatchNorm2d(eval) / MaxPool2d / LSTM / Linear
  *     semantics (gate order i,f,g,o; -inf pooling pad), fp32 arithmetic.
  *
