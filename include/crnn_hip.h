@@ -186,10 +186,18 @@ CRNN_API int64_t crnn_noalloc_workspace_bytes(const crnn_handle* h, int32_t n, i
  * service wants to see; 0 in normal operation).  No reference counterpart. */
 CRNN_API int64_t crnn_split_timeouts(const crnn_handle* h);
 
+/* Diagnostic: the load-time channel equalisation's factors (crnn_load_weights rescales every hidden channel by an exact
+ * power of two on the producing side and its inverse on the consuming side -- the network function is unchanged).
+ * layer 0..6 = conv0..conv6 output channels, 7 = the first embedding's outputs.  Copies min(cap, channels) factors to out
+ * and returns the number of channels, or a negative status (CRNN_ERR_STATE before crnn_load_weights).  Host-only, needs no
+ * GPU.  No reference counterpart (the reference has no reduced-precision path to protect). */
+CRNN_API int crnn_channel_scales(const crnn_handle* h, int32_t layer, float* out, int32_t cap);
+
 /* Debug taps for layer-by-layer parity: runs crnn_forward_device's network on normalised fp32
  * host input x [n,32,w] and copies stage `stage` (0 pool0, 1 pool1, 2 relu2, 3 pool2, 4 relu4,
  * 5 pool3, 6 relu6/sequence, 7 lstm0 out, 8 lstm0 recurrent, 9 lstm1 recurrent, 10 logits),
- * NHWC / batch-major as stored on the device, to out_host (capacity out_floats). */
+ * NHWC / batch-major as stored on the device, to out_host (capacity out_floats); the channel equalisation's factors are
+ * divided out, so the values are the reference's activations. */
 CRNN_API int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const int32_t* widths,
                      int32_t stage, float* out_host, int64_t out_floats);
 

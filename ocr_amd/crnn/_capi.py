@@ -19,7 +19,8 @@ FP32, BF16 = 0, 1
 SYMBOLS = ["crnn_create", "crnn_load_weights", "crnn_resized_width", "crnn_out_len", "crnn_preprocess",
            "crnn_predict_batch", "crnn_set_page", "crnn_predict_rects", "crnn_predict_page", "crnn_forward_device", "crnn_debug_stage", "crnn_synchronize", "crnn_stream", "crnn_lanes",
            "crnn_last_timing", "crnn_set_profiling", "crnn_last_kernel_times", "crnn_last_error", "crnn_destroy",
-           "crnn_next_lane", "crnn_split_timeouts", "crnn_forward_device_noalloc", "crnn_noalloc_workspace_bytes"]
+           "crnn_next_lane", "crnn_split_timeouts", "crnn_forward_device_noalloc", "crnn_noalloc_workspace_bytes",
+           "crnn_channel_scales"]
 
 
 class Config(C.Structure):
@@ -170,6 +171,8 @@ def lib():
     L.crnn_forward_device_noalloc.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i32]
     L.crnn_noalloc_workspace_bytes.restype = C.c_int64
     L.crnn_noalloc_workspace_bytes.argtypes = [vp, i32, i32]
+    L.crnn_channel_scales.restype = C.c_int
+    L.crnn_channel_scales.argtypes = [vp, i32, C.POINTER(C.c_float), i32]
     _lib = L
     return L
 

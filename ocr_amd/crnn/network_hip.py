@@ -399,6 +399,13 @@ class CRNN(object):
         """How often the hidden-split recurrence gave up and a batch was repeated (0 in normal operation)."""
         return int(self._lib.crnn_split_timeouts(self._h))
 
+    def channel_scales(self, layer):
+        """The load-time channel equalisation's power-of-two factors of conv `layer` (0..6) / the first embedding (7)."""
+        import ctypes as C
+        buf = (C.c_float * 512)()
+        n = _capi.check(self._h, self._lib.crnn_channel_scales(self._h, layer, buf, 512))
+        return np.array(buf[:n], np.float32)
+
     def texts_from_labels(self, lab, ln):
         """Host arrays lab [n,T] / ln [n] (as copied back from forward_device) -> list of str."""
         lab = np.asarray(lab)

@@ -128,6 +128,11 @@ struct crnn_handle {
   hipEvent_t split_ev = nullptr;
   std::atomic<int64_t> split_timeouts{0};   // batches repeated because the hidden-split recurrence gave up (crnn_split_timeouts)
   bool wino_fused = true;   // GEMM + output transform in one kernel (CRNN_WINO_FUSED=0: separate kernels)
+  // Load-time channel equalisation (equalize_channels below; CRNN_EQUALIZE=0: off): the power-of-two factor that
+  // output channel c of conv i (chan_scale[i]) / of the first embedding (chan_scale[7]) carries relative to the
+  // reference's activation.  crnn_debug_stage divides it out again; nothing else sees it.
+  bool equalize = true;
+  std::vector<float> chan_scale[8];
   // bf16 copies (precision == CRNN_BF16): conv1..6, W_ih, embeddings / linear, packed W_hh
   std::vector<uint16_t> hb_conv_w[7], hb_wih[2], hb_whhp[2], hb_emb_w[2], hb_lin_w;
 
@@ -916,6 +921,96 @@ int check_images(crnn_handle* h, const uint8_t* const* imgs, const int32_t* heig
   return 0;
 }
 
+// crnn_debug_stage reports the reference's activations: stages 0..6 are conv0..conv6 outputs (channels innermost), stage 7
+// the first embedding's; the equalisation factors of their channels (exact powers of two) are divided out on the host.
+void unscale_stage(const crnn_handle* h, int stage, float* out, size_t count) {
+  if (stage > 7) return;
+  const std::vector<float>& cs = h->chan_scale[stage];
+  const size_t C = cs.size();
+  if (!C) return;
+  bool any = false;
+  for (float v : cs) any |= v != 1.f;
+  if (!any) return;
+  for (size_t i = 0; i < count; i++) out[i] /= cs[i % C];
+}
+
+// Load-time channel equalisation.  Between two layers joined only by ReLU / LeakyReLU and max-pooling, output channel c
+// of the producer may be multiplied by any s_c > 0 if the consumer's weights for input channel c are divided by it: the
+// network computes the same function (network_torch.py:53-78: conv -> [BN] -> ReLU -> [pool] -> conv; the first
+// embedding -> the second LSTM's input projection is plain linear, :26-32).  With s_c a power of two the change is exact
+// in binary floating point, so an fp32 evaluation of the rescaled network gives the same bits as before (no overflow or
+// underflow at these magnitudes).  A checkpoint uses that freedom arbitrarily -- a BatchNorm gain of 1e-3 in one channel and
+// 1e3 in its neighbour, made up for in the next layer's columns -- and that is what hurts the split-fp16 GEMM operands,
+// whose scale is one power of two per weight tensor / per activation tile: an element 2^-20 below the block maximum keeps 19
+// significant bits instead of 22.  So the freedom is spent here, once, on the host: s_c = sqrt(column range of the consumer
+// / row range of the producer), rounded to a power of two, makes the two ranges of every hidden channel equal (Nagel et al.
+// 2019, "cross-layer equalization", there for int8 inference); a few sweeps over the chain conv0 .. conv6 -> W_ih (layer 0)
+// or the dense head, and emb0 -> W_ih (layer 1).  Channels that are dead on either side are left alone.
+// h->chan_scale keeps the accumulated factors (crnn_debug_stage reports the reference's activations).
+void equalize_channels(crnn_handle* h, std::vector<double>* fw, std::vector<double>* fb) {
+  const int nh = 256;
+  auto p2 = [](double x) { return std::exp2(std::nearbyint(std::log2(x))); };
+  for (int sweep = 0; sweep < 16; sweep++) {
+    bool changed = false;
+    for (int i = 0; i < 8; i++) {
+      // producer rows: conv i (i < 7) or emb0 (i == 7); consumer columns: conv i+1, W_ih[0] / linear (after conv6), W_ih[1]
+      if (i == 7 && !h->cfg.lstm) continue;
+      const int C = i < 7 ? NM[i] : nh;
+      std::vector<double> r1(C, 0.0), r2(C, 0.0);
+      const int cin = i == 0 ? 1 : (i < 7 ? NM[i - 1] : 2 * nh);
+      const size_t per = i < 7 ? (size_t)cin * KS[i] * KS[i] : (size_t)2 * nh;
+      for (int c = 0; c < C; c++)
+        for (size_t j = 0; j < per; j++)
+          r1[c] = std::max(r1[c], i < 7 ? std::fabs(fw[i][(size_t)c * per + j]) : (double)std::fabs(h->h_emb_w[0][(size_t)c * per + j]));
+      std::vector<float>* lin = nullptr;      // a [rows][C] consumer
+      if (i < 6) {
+        const int co = NM[i + 1], kk = KS[i + 1] * KS[i + 1];
+        for (int o = 0; o < co; o++)
+          for (int c = 0; c < C; c++)
+            for (int t = 0; t < kk; t++) r2[c] = std::max(r2[c], std::fabs(fw[i + 1][((size_t)o * C + c) * kk + t]));
+      } else {
+        lin = i == 7 ? &h->h_wih[1] : (h->cfg.lstm ? &h->h_wih[0] : &h->h_lin_w);
+        const size_t rows = lin->size() / C;
+        for (size_t o = 0; o < rows; o++)
+          for (int c = 0; c < C; c++) r2[c] = std::max(r2[c], (double)std::fabs((*lin)[o * C + c]));
+      }
+      std::vector<double> sc(C, 1.0);
+      for (int c = 0; c < C; c++) {
+        if (!(r1[c] > 0.0) || !(r2[c] > 0.0) || !std::isfinite(r1[c]) || !std::isfinite(r2[c])) continue;
+        double v = p2(std::sqrt(r2[c] / r1[c]));
+        const double tot = v * (double)h->chan_scale[i][c];
+        if (!(tot > 0x1p-60 && tot < 0x1p60)) v = 1.0;       // keep the accumulated factor in a safe range
+        sc[c] = v;
+        if (v != 1.0) changed = true;
+      }
+      for (int c = 0; c < C; c++) {
+        if (sc[c] == 1.0) continue;
+        h->chan_scale[i][c] = (float)((double)h->chan_scale[i][c] * sc[c]);
+        if (i < 7) {
+          for (size_t j = 0; j < per; j++) fw[i][(size_t)c * per + j] *= sc[c];
+          fb[i][c] *= sc[c];
+        } else {
+          for (size_t j = 0; j < per; j++) h->h_emb_w[0][(size_t)c * per + j] = (float)((double)h->h_emb_w[0][(size_t)c * per + j] * sc[c]);
+          h->h_emb_b[0][c] = (float)((double)h->h_emb_b[0][c] * sc[c]);
+        }
+      }
+      if (i < 6) {
+        const int co = NM[i + 1], kk = KS[i + 1] * KS[i + 1];
+        for (int o = 0; o < co; o++)
+          for (int c = 0; c < C; c++)
+            if (sc[c] != 1.0)
+              for (int t = 0; t < kk; t++) fw[i + 1][((size_t)o * C + c) * kk + t] /= sc[c];
+      } else {
+        const size_t rows = lin->size() / C;
+        for (size_t o = 0; o < rows; o++)
+          for (int c = 0; c < C; c++)
+            if (sc[c] != 1.0) (*lin)[o * C + c] = (float)((double)(*lin)[o * C + c] / sc[c]);
+      }
+    }
+    if (!changed) break;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -954,6 +1049,7 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   if (const char* e = getenv("CRNN_WINO6")) h->wino6 = atoi(e) != 0;
   if (const char* e = getenv("CRNN_F16X3")) h->h3 = atoi(e) != 0;
   if (const char* e = getenv("CRNN_REC_H3")) h->rec_h3 = atoi(e) != 0;
+  if (const char* e = getenv("CRNN_EQUALIZE")) h->equalize = atoi(e) != 0;
   if (cfg->precision != CRNN_FP32) h->h3 = false;
   if (const char* e = getenv("CRNN_CLS_FILTER")) h->cls_filter = atoi(e) != 0;
   if (cfg->precision != CRNN_FP32) h->cls_filter = false;
@@ -982,6 +1078,9 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
   }
   std::string err;
   const int nh = 256, nclass = h->cfg.nclass;
+  // ---- phase A: stage.  Conv weights with BatchNorm2d(eval) folded -- y = (x - mean) / sqrt(var + eps) * gamma + beta --
+  // in float64, reference layout [co][cin][ky][kx] (fw) + bias (fb); LSTM / linear weights as they come.
+  std::vector<double> fw[7], fb[7];
   for (int i = 0; i < 7; i++) {
     const int cin = i == 0 ? 1 : NM[i - 1], co = NM[i], k = KS[i];
     const std::string pc = "cnn.conv" + std::to_string(i) + ".";
@@ -997,20 +1096,68 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
       if (!var) b = nullptr;
     }
     if (!b) return fail(h, CRNN_ERR_ARG, err);
-    // BatchNorm2d(eval): y = (x - mean) / sqrt(var + eps) * gamma + beta, folded into w, b
-    h->h_conv_w[i].assign((size_t)co * k * k * cin, 0.f);
-    h->h_conv_b[i].assign(co, 0.f);
+    const size_t per = (size_t)cin * k * k;
+    fw[i].resize((size_t)co * per);
+    fb[i].resize(co);
     for (int o = 0; o < co; o++) {
       double sc = 1.0, sh = 0.0;
       if (g) {
         sc = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
         sh = (double)bt[o] - (double)mu[o] * sc;
       }
-      h->h_conv_b[i][o] = (float)((double)b[o] * sc + sh);
+      fb[i][o] = (double)b[o] * sc + sh;
+      for (size_t j = 0; j < per; j++) fw[i][(size_t)o * per + j] = (double)w[(size_t)o * per + j] * sc;
+    }
+  }
+  const float* whh_src[2][2] = {};
+  if (h->cfg.lstm) {
+    for (int l = 0; l < 2; l++) {
+      const int nin = l == 0 ? 512 : nh, nout = l == 0 ? nh : nclass;
+      const std::string pr = "rnn." + std::to_string(l) + ".rnn.";
+      const float *wih[2], *bih[2], *bhh[2];
+      for (int d = 0; d < 2; d++) {
+        const std::string sfx = d ? "_reverse" : "";
+        wih[d] = find_tensor(m, pr + "weight_ih_l0" + sfx, {4 * nh, nin}, err);
+        whh_src[l][d] = wih[d] ? find_tensor(m, pr + "weight_hh_l0" + sfx, {4 * nh, nh}, err) : nullptr;
+        bih[d] = whh_src[l][d] ? find_tensor(m, pr + "bias_ih_l0" + sfx, {4 * nh}, err) : nullptr;
+        bhh[d] = bih[d] ? find_tensor(m, pr + "bias_hh_l0" + sfx, {4 * nh}, err) : nullptr;
+        if (!bhh[d]) return fail(h, CRNN_ERR_ARG, err);
+      }
+      h->h_wih[l].resize((size_t)2 * 4 * nh * nin);
+      h->h_bih[l].resize((size_t)2 * 4 * nh);
+      for (int d = 0; d < 2; d++) {
+        memcpy(h->h_wih[l].data() + (size_t)d * 4 * nh * nin, wih[d], sizeof(float) * 4 * nh * nin);
+        for (int j = 0; j < 4 * nh; j++) h->h_bih[l][(size_t)d * 4 * nh + j] = bih[d][j] + bhh[d][j];
+      }
+      const std::string pe = "rnn." + std::to_string(l) + ".embedding.";
+      const float* ew = find_tensor(m, pe + "weight", {nout, 2 * nh}, err);
+      const float* eb = ew ? find_tensor(m, pe + "bias", {nout}, err) : nullptr;
+      if (!eb) return fail(h, CRNN_ERR_ARG, err);
+      h->h_emb_w[l].assign(ew, ew + (size_t)nout * 2 * nh);
+      h->h_emb_b[l].assign(eb, eb + nout);
+    }
+  } else {
+    const float* lw = find_tensor(m, "linear.weight", {nclass, 2 * nh}, err);
+    const float* lb = lw ? find_tensor(m, "linear.bias", {nclass}, err) : nullptr;
+    if (!lb) return fail(h, CRNN_ERR_ARG, err);
+    h->h_lin_w.assign(lw, lw + (size_t)nclass * 2 * nh);
+    h->h_lin_b.assign(lb, lb + nclass);
+  }
+  // ---- phase B: equalise the hidden channels (exact power-of-two reparametrisation; see equalize_channels)
+  for (int i = 0; i < 7; i++) h->chan_scale[i].assign(NM[i], 1.f);
+  h->chan_scale[7].assign(nh, 1.f);
+  if (h->equalize) equalize_channels(h, fw, fb);
+  // ---- phase C: the layouts the kernels read
+  for (int i = 0; i < 7; i++) {
+    const int cin = i == 0 ? 1 : NM[i - 1], co = NM[i], k = KS[i];
+    h->h_conv_w[i].assign((size_t)co * k * k * cin, 0.f);
+    h->h_conv_b[i].assign(co, 0.f);
+    for (int o = 0; o < co; o++) {
+      h->h_conv_b[i][o] = (float)fb[i][o];
       for (int c = 0; c < cin; c++)
         for (int ky = 0; ky < k; ky++)
           for (int kx = 0; kx < k; kx++) {
-            const float v = (float)((double)w[(((size_t)o * cin + c) * k + ky) * k + kx] * sc);
+            const float v = (float)fw[i][(((size_t)o * cin + c) * k + ky) * k + kx];
             if (i == 0) {
               h->h_conv_w[0][(size_t)(ky * 3 + kx) * 64 + o] = v;  // [tap][co] for the direct kernel
             } else {
@@ -1033,22 +1180,14 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
   for (int i = 1; i <= 5; i++) {
     if (!((h->wino_mask >> i) & 1u)) continue;
     const int cin = NM[i - 1], co = NM[i];
-    const std::string pc = "cnn.conv" + std::to_string(i) + ".";
-    const float* w = m[pc + "weight"]->data;
-    const float *g = nullptr, *var = nullptr;
-    if (HAS_BN[i]) {
-      const std::string pb = "cnn.batchnorm" + std::to_string(i) + ".";
-      g = m[pb + "weight"]->data;
-      var = m[pb + "running_var"]->data;
-    }
+    const std::vector<double>& w = fw[i];
     static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     h->h_wino[i].assign((size_t)16 * co * cin, 0.f);
     for (int o = 0; o < co; o++) {
-      const double sc = g ? (double)g[o] / std::sqrt((double)var[o] + 1e-5) : 1.0;
       for (int c = 0; c < cin; c++) {
         double gg[3][3], t[4][3];
         for (int a = 0; a < 3; a++)
-          for (int b = 0; b < 3; b++) gg[a][b] = (double)w[(((size_t)o * cin + c) * 3 + a) * 3 + b] * sc;
+          for (int b = 0; b < 3; b++) gg[a][b] = w[(((size_t)o * cin + c) * 3 + a) * 3 + b];
         for (int a = 0; a < 4; a++)
           for (int b = 0; b < 3; b++) t[a][b] = G[a][0] * gg[0][b] + G[a][1] * gg[1][b] + G[a][2] * gg[2][b];
         for (int a = 0; a < 4; a++)
@@ -1063,23 +1202,15 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
   for (int i = 1; i <= 5; i++) {
     if (!((h->wino4_mask >> i) & 1u)) continue;
     const int cin = NM[i - 1], co = NM[i];
-    const std::string pc = "cnn.conv" + std::to_string(i) + ".";
-    const float* w = m[pc + "weight"]->data;
-    const float *g = nullptr, *var = nullptr;
-    if (HAS_BN[i]) {
-      const std::string pb = "cnn.batchnorm" + std::to_string(i) + ".";
-      g = m[pb + "weight"]->data;
-      var = m[pb + "running_var"]->data;
-    }
+    const std::vector<double>& w = fw[i];
     static const double G[6][3] = {{1, 0, 0},          {-1.0 / 3, -1.0 / 3, -1.0 / 3}, {1.0 / 3, -1.0 / 3, 1.0 / 3},
                                    {1.0 / 15, 2.0 / 15, 4.0 / 15}, {-16.0 / 15, 8.0 / 15, -4.0 / 15}, {0, 0, 1}};
     h->h_wino4[i].assign((size_t)36 * co * cin, 0.f);
     for (int o = 0; o < co; o++) {
-      const double sc = g ? (double)g[o] / std::sqrt((double)var[o] + 1e-5) : 1.0;
       for (int c = 0; c < cin; c++) {
         double gg[3][3], t[6][3];
         for (int a = 0; a < 3; a++)
-          for (int b = 0; b < 3; b++) gg[a][b] = (double)w[(((size_t)o * cin + c) * 3 + a) * 3 + b] * sc;
+          for (int b = 0; b < 3; b++) gg[a][b] = w[(((size_t)o * cin + c) * 3 + a) * 3 + b];
         for (int a = 0; a < 6; a++)
           for (int b = 0; b < 3; b++) t[a][b] = G[a][0] * gg[0][b] + G[a][1] * gg[1][b] + G[a][2] * gg[2][b];
         for (int a = 0; a < 6; a++)
@@ -1092,20 +1223,14 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
   // conv6 as F(4,2) along the width: U6[b][o][ky * 512 + c] = sum_l G[b][l] w[o][c][ky][l]
   if (h->wino6) {
     const int cin = NM[5], co = NM[6];
-    const float* w = m["cnn.conv6.weight"]->data;
-    const float *g = nullptr, *var = nullptr;
-    if (HAS_BN[6]) {
-      g = m["cnn.batchnorm6.weight"]->data;
-      var = m["cnn.batchnorm6.running_var"]->data;
-    }
+    const std::vector<double>& w = fw[6];
     static const double G[5][2] = {{0.5, 0}, {-0.5, -0.5}, {-1.0 / 6, 1.0 / 6}, {1.0 / 6, 1.0 / 3}, {0, 1}};
     h->h_wino4[6].assign((size_t)5 * co * 2 * cin, 0.f);
     for (int o = 0; o < co; o++) {
-      const double sc = g ? (double)g[o] / std::sqrt((double)var[o] + 1e-5) : 1.0;
       for (int c = 0; c < cin; c++)
         for (int ky = 0; ky < 2; ky++) {
-          const double w0 = (double)w[(((size_t)o * cin + c) * 2 + ky) * 2 + 0] * sc;
-          const double w1 = (double)w[(((size_t)o * cin + c) * 2 + ky) * 2 + 1] * sc;
+          const double w0 = w[(((size_t)o * cin + c) * 2 + ky) * 2 + 0];
+          const double w1 = w[(((size_t)o * cin + c) * 2 + ky) * 2 + 1];
           for (int b = 0; b < 5; b++)
             h->h_wino4[6][((size_t)b * co + o) * 2 * cin + (size_t)ky * cin + c] = (float)(G[b][0] * w0 + G[b][1] * w1);
         }
@@ -1120,42 +1245,13 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
     }
   if (h->cfg.lstm) {
     for (int l = 0; l < 2; l++) {
-      const int nin = l == 0 ? 512 : nh, nout = l == 0 ? nh : nclass;
-      const std::string pr = "rnn." + std::to_string(l) + ".rnn.";
-      const float *wih[2], *whh[2], *bih[2], *bhh[2];
-      for (int d = 0; d < 2; d++) {
-        const std::string sfx = d ? "_reverse" : "";
-        wih[d] = find_tensor(m, pr + "weight_ih_l0" + sfx, {4 * nh, nin}, err);
-        whh[d] = wih[d] ? find_tensor(m, pr + "weight_hh_l0" + sfx, {4 * nh, nh}, err) : nullptr;
-        bih[d] = whh[d] ? find_tensor(m, pr + "bias_ih_l0" + sfx, {4 * nh}, err) : nullptr;
-        bhh[d] = bih[d] ? find_tensor(m, pr + "bias_hh_l0" + sfx, {4 * nh}, err) : nullptr;
-        if (!bhh[d]) return fail(h, CRNN_ERR_ARG, err);
-      }
-      h->h_wih[l].resize((size_t)2 * 4 * nh * nin);
-      h->h_bih[l].resize((size_t)2 * 4 * nh);
-      for (int d = 0; d < 2; d++) {
-        memcpy(h->h_wih[l].data() + (size_t)d * 4 * nh * nin, wih[d], sizeof(float) * 4 * nh * nin);
-        for (int j = 0; j < 4 * nh; j++) h->h_bih[l][(size_t)d * 4 * nh + j] = bih[d][j] + bhh[d][j];
-      }
       h->h_whhp[l].resize((size_t)2 * 4 * nh * nh);
-      pack_whh(whh[0], whh[1], h->h_whhp[l].data());
+      pack_whh(whh_src[l][0], whh_src[l][1], h->h_whhp[l].data());
       if (h->h3 && h->rec_h3) {
         h->h_whh3[l].resize((size_t)2 * 4 * nh * nh * 2);
-        h->whh3_unscale[l] = pack_whh_h3(whh[0], whh[1], h->h_whh3[l].data());
+        h->whh3_unscale[l] = pack_whh_h3(whh_src[l][0], whh_src[l][1], h->h_whh3[l].data());
       }
-      const std::string pe = "rnn." + std::to_string(l) + ".embedding.";
-      const float* ew = find_tensor(m, pe + "weight", {nout, 2 * nh}, err);
-      const float* eb = ew ? find_tensor(m, pe + "bias", {nout}, err) : nullptr;
-      if (!eb) return fail(h, CRNN_ERR_ARG, err);
-      h->h_emb_w[l].assign(ew, ew + (size_t)nout * 2 * nh);
-      h->h_emb_b[l].assign(eb, eb + nout);
     }
-  } else {
-    const float* lw = find_tensor(m, "linear.weight", {nclass, 2 * nh}, err);
-    const float* lb = lw ? find_tensor(m, "linear.bias", {nclass}, err) : nullptr;
-    if (!lb) return fail(h, CRNN_ERR_ARG, err);
-    h->h_lin_w.assign(lw, lw + (size_t)nclass * 2 * nh);
-    h->h_lin_b.assign(lb, lb + nclass);
   }
   if (h->h3 && h->cfg.lstm) {
     for (int l = 0; l < 2; l++) {
@@ -1517,6 +1613,14 @@ int crnn_forward_device_noalloc(crnn_handle* h, const uint8_t* d_gray, int32_t n
   return 0;
 }
 
+int crnn_channel_scales(const crnn_handle* h, int32_t layer, float* out, int32_t cap) {
+  if (!h || layer < 0 || layer > 7 || (cap > 0 && !out)) return CRNN_ERR_ARG;
+  if (!h->loaded) return fail(h, CRNN_ERR_STATE, "no weights loaded");
+  const std::vector<float>& cs = h->chan_scale[layer];
+  for (int i = 0; i < cap && i < (int)cs.size(); i++) out[i] = cs[i];
+  return (int)cs.size();
+}
+
 int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const int32_t* widths, int32_t stage,
                      float* out_host, int64_t out_floats) {
   if (!h) return CRNN_ERR_ARG;
@@ -1548,9 +1652,11 @@ int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const
       const uint32_t u = (uint32_t)tmp[i] << 16;
       memcpy(&out_host[i], &u, 4);
     }
+    unscale_stage(h, stage, out_host, tmp.size());
     return 0;
   }
   HIPCHK(h, hipMemcpy(out_host, tl_cur->st[stage], tl_cur->st_floats[stage] * sizeof(float), hipMemcpyDeviceToHost));
+  unscale_stage(h, stage, out_host, tl_cur->st_floats[stage]);
   return 0;
 }
 

@@ -16,13 +16,31 @@ import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
-PK = re.compile(r"\bv_pk_(fma|mul|add)_f32\b")
+# v_pk_mov_b32 moves fp32 lanes with the same op_sel source selection and goes through the same packed data path
+PK = re.compile(r"\bv_pk_(fma_f32|mul_f32|add_f32|mov_b32)\b")
 SEL = re.compile(r"op_sel:\[([01,]+)\]")
+
+
+def llvm_bin():
+    """llvm-objdump's directory: $LLVM_BIN, else beside the hipcc the Makefile used ($HIPCC: <rocm>/bin/hipcc ->
+    <rocm>/lib/llvm/bin), else /opt/rocm."""
+    cands = [os.environ.get("LLVM_BIN")]
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc")
+    if hipcc:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for c in cands:
+        if c and os.path.exists(os.path.join(c, "llvm-objdump")):
+            return c
+    return None
 
 
 def main():
     lib = sys.argv[1]
+    LLVM = llvm_bin()
+    if LLVM is None:
+        print("check_isa: llvm-objdump not found (set LLVM_BIN to the ROCm LLVM bin directory); the library was NOT checked")
+        return 2
     bad = []
     n_pk = 0
     with tempfile.TemporaryDirectory() as td:
