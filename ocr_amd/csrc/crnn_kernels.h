@@ -222,7 +222,8 @@ struct Wino4Fused {
 };
 void launch_wino4_fused(const Wino4Fused& p, hipStream_t s);
 inline long wino4_tiles(int B, int H, int W) { return (long)B * (H / 4) * ((W + 3) / 4); }
-inline long wino4_pad(long tiles) { return (tiles + 127) / 128 * 128; }
+// rows of V / M: tiles rounded up to the GEMM's unit height -- 256 where the ping-pong GEMM runs (from 1024 tiles), else 128
+inline long wino4_pad(long tiles) { return tiles > 896 ? (tiles + 255) / 256 * 256 : (tiles + 127) / 128 * 128; }
 // vs != nullptr: V in the f16x3 format, vs[tile] = 1 / (the tile's scale)
 void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s, float* vs = nullptr);
 // conv6 as 1-D F(4,2): x NHWC [B,2,W,C] -> V[5][pad(B*ceil((W-1)/4))][2*C]; M[5][..][Cout] -> y [B*(W-1)][Cout] + bias, act

@@ -1709,6 +1709,211 @@ __global__ __launch_bounds__(512 + 64 * NLW, 1) void wino4_gemm_h3_lw_kernel(con
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The f16x3 component GEMMs, ping-pong form (round 3; CRNN_GEMM_PP=0 keeps the form above).  Units of 256 tiles x 128
+// channels; eight MFMA waves as 4 (tiles) x 2 (channels), wave tile 64 x 64 = four accumulators (8 fragment reads per 12
+// MFMAs instead of 6 per 6), in TWO GROUPS of four -- one wave of each group on every SIMD -- that run one slot apart: while
+// group 0 issues the 12 MFMAs of a k16 half-step, group 1 reads the fragments of its next one, and the other way round, a
+// barrier between slots.  A SIMD's matrix pipe always has one wave's MFMAs, the other wave's fragment-read latency is under
+// them, and one fragment register set is enough (134 registers).  Four loader waves issue the direct-to-LDS loads: 48 pieces
+// of 1 KiB per K step into three stages of 48 KB (A rows first, then B rows; the row-pair / XOR-swizzled layout of the
+// kernels above).  Barrier B_t opens slot t:
+//   group 0   reads (K step s, half j) in slot 4 s + 2 j, waits for them and issues the MFMAs in the slot after;
+//   group 1   the same one slot later (it passes one extra barrier at the start, group 0 one at the end);
+//   loaders   the batch of K step s + 2 -- stage (s + 2) % 3, last read in K step s - 1, and those reads were waited for by
+//             slot 4 s at the latest -- goes out in slots 4 s + 1 .. 4 s + 3; then vmcnt(12): the batch of K step s + 1 has
+//             landed before B_{4 s + 4}, and group 0 first reads it in slot 4 s + 4 (a read comes one slot after the wait
+//             that retires its stage, never in the same slot).
+// The MFMAs take the V fragment first, so a lane ends with one channel of rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of a
+// 32 x 32 product: a dword store instruction writes two full 128-byte lines of M, no transpose through LDS.
+// Measured in tools/h3_gemm_bench.hip against the loader-wave form in the same process (conv5 / conv3 / conv4 / conv6
+// shapes at 256 lines): 0.305 / 0.181 / 0.182 / 0.306 ms against 0.348 / 0.221 / 0.219 / 0.338.  In core cycles the kernel
+// is within 30 % of the MFMA issue time; what it lacks in wall time is clock: s_memtime against s_memrealtime inside the
+// kernel gives 1.0-1.3 GHz ("the power wall").
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768, 1) void wino4_gemm_h3_pp_kernel(const Wino4Gemm p) {
+  constexpr int TBM = 256, TBN = 128, SA = TBM * 32, SB = TBN * 32, STG = SA + SB;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
+  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  const int nk = p.Cin / BK;
+  const int nit = my_units * nk;
+  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) __attribute__((always_inline)) {
+    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
+    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.Cin * 4ull;
+    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.Cin * 4ull;
+    m = (unsigned long long)p.M +
+        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
+  };
+  if (wave >= 8) {
+    const int lw = wave - 8;
+    unsigned offa[8], offb[4];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int P = (lw * 8 + q) * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      offa[q] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int P = (lw * 4 + q) * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      offb[q] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
+    }
+    const unsigned ldsA = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)(lw * 8) * 1024u;
+    const unsigned ldsB = (unsigned)(size_t)(lds_ptr_t)smem + SA * 4 + (unsigned)(lw * 4) * 1024u;
+    auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+      unsigned m0_saved;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    };
+    int l_u = L, l_k0 = 0, lst = 0;
+    unsigned long long pa, pb, pm;
+    bases(l_u, pa, pb, pm);
+    auto part = [&](int which) __attribute__((always_inline)) {
+      const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const unsigned so = (unsigned)lst * (STG * 4);
+      if (which == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) dma(a_rsrc, ldsA + so + q * 1024, offa[q], l_k0 * 4);
+      } else if (which == 1) {
+#pragma unroll
+        for (int q = 4; q < 8; q++) dma(a_rsrc, ldsA + so + q * 1024, offa[q], l_k0 * 4);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) dma(b_rsrc, ldsB + so + q * 1024, offb[q], l_k0 * 4);
+        l_k0 += BK;
+        lst = lst == 2 ? 0 : lst + 1;
+        if (l_k0 == p.Cin) {
+          l_k0 = 0;
+          if (l_u + G < NU) l_u += G;
+          bases(l_u, pa, pb, pm);
+        }
+      }
+    };
+    part(0); part(1); part(2);
+    if (nit > 1) { part(0); part(1); part(2); }
+    if (nit > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // B_0
+#pragma unroll 1
+    for (int s = 0; s < nit; s++) {
+      const bool more = s + 2 < nit;
+      __builtin_amdgcn_s_barrier();
+      if (more) part(0);
+      __builtin_amdgcn_s_barrier();
+      if (more) part(1);
+      __builtin_amdgcn_s_barrier();
+      if (more) {
+        part(2);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+  const int grp = wave >> 2, wm = wave & 3, wn = grp;
+  int ahi[2], alo[2], bhi[2], blo[2];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 64 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = 4 * j + 2 * h;
+      ahi[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | c) ^ ((Ra >> 1) & 15)) << 2);
+      alo[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (c + 1)) ^ ((Ra >> 1) & 15)) << 2);
+      bhi[j] = SA + (Rb >> 1) * 64 + (((((Rb & 1) << 3) | c) ^ ((Rb >> 1) & 15)) << 2);
+      blo[j] = SA + (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (c + 1)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+  int kc = 0, c_u = L;
+  const unsigned moff = (unsigned)((wm * 64 + 4 * (lane >> 5)) * p.N + wn * 64 + (lane & 31));
+  auto flush = [&]() __attribute__((always_inline)) {
+    unsigned long long ua, ub, pm;
+    bases(c_u, ua, ub, pm);
+    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+#ifdef H3_NOSTORE
+          if (acc[mt][nt][r] == 12345.f)
+#endif
+          dst[(mt * 32 + (r & 3) + 8 * (r >> 2)) * p.N + nt * 32] = acc[mt][nt][r];
+          acc[mt][nt][r] = 0.f;
+        }
+    kc = 0;
+    c_u += G;
+  };
+  f16x8 ah[2], al[2], bh[2], bl[2];
+  auto half = [&](int stage, int j) __attribute__((always_inline)) {
+    const float* sb = smem + stage * STG;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      ah[t] = *(const f16x8*)(sb + ahi[j] + 1024 * t);
+      al[t] = *(const f16x8*)(sb + alo[j] + 1024 * t);
+      bh[t] = *(const f16x8*)(sb + bhi[j] + 1024 * t);
+      bl[t] = *(const f16x8*)(sb + blo[j] + 1024 * t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    // small terms first (lo hi, hi lo, then hi hi); four accumulators, so equal accumulators are four MFMAs apart
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto step = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value;
+    half(st, 0);
+    __builtin_amdgcn_s_barrier();
+    half(st, 1);
+    if (++kc == nk) flush();
+    __builtin_amdgcn_s_barrier();
+  };
+  __builtin_amdgcn_s_barrier();                            // B_0
+  if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one slot behind
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
 // ---------------------------------------------------------------------------
 // F(4x4,3x3) component GEMMs AND output transform in one kernel (f16x3 operands): the product tensor M (2.25x the layer's
 // output, written and read back by the three-kernel form) never exists.  Keeping all 36 products of an output block in
@@ -2416,7 +2621,18 @@ void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
   if (p.h3) {   // operands in the f16x3 format (N % 128 == 0 checked by the caller)
     const int u3 = p.ncomp * (p.ntile_pad / 128) * (p.N / 128);
     static const int h3lw = getenv("CRNN_H3_LW") ? atoi(getenv("CRNN_H3_LW")) : 256;   // loader waves from this K (0 = never)
-    if (h3lw > 0 && p.Cin >= h3lw)
+    const char* ppe = getenv("CRNN_GEMM_PP");      // read per launch: bench.py switches it between handles for its A/B line
+    const bool pp = !(ppe && atoi(ppe) == 0);
+    // the ping-pong form: 256-tile units (wino4_pad rounds to 256 from 1024 tiles up).  Measured alone on the device at 256
+    // lines against the loader-wave form: conv4 0.162 against 0.181 ms, conv5 0.250 against 0.277, but conv3 (N = 256: a unit
+    // is only 8 K steps before its 64 store instructions per wave) 0.193 against 0.169 and conv6 (K = 1024, 5 components)
+    // 0.090 against 0.083 -- so it takes the layers with N >= 512 and K <= 512.  In the four-lane pipeline the two forms
+    // are within 0.5 % of each other (the chip is power-bound there).  CRNN_GEMM_PP=2: every layer it can take.
+    const int ppm = ppe ? atoi(ppe) : 1;
+    if (pp && p.Cin >= 256 && p.ntile_pad >= 1024 && p.ntile_pad % 256 == 0 && (ppm == 2 || (p.N >= 512 && p.Cin <= 512))) {
+      const int u2 = p.ncomp * (p.ntile_pad / 256) * (p.N / 128);
+      hipLaunchKernelGGL(wino4_gemm_h3_pp_kernel, dim3(u2 < persistent_blocks() ? 8 * ((u2 + 7) / 8) : persistent_blocks()), dim3(768), 0, s, p);
+    } else if (h3lw > 0 && p.Cin >= h3lw)
       hipLaunchKernelGGL((wino4_gemm_h3_lw_kernel<4>), dim3(u3 < persistent_blocks() ? 8 * ((u3 + 7) / 8) : persistent_blocks()), dim3(768), 0, s, p);
     else
       hipLaunchKernelGGL(wino4_gemm_h3_kernel, dim3(u3 < persistent_blocks() ? 8 * ((u3 + 7) / 8) : persistent_blocks()), dim3(512), 0, s, p);

@@ -27,6 +27,7 @@ struct H3Gemm {
   float* M;        // [ncomp][ntile_pad][N]
   int ntile_pad, N, K, ncomp;
   float unscale;   // 1 / (s_V s_U)
+  float* clk;      // PP_CLOCK: block 0's core cycles and 100 MHz ticks
 };
 
 constexpr int BK = 32;
@@ -393,6 +394,476 @@ __global__ __launch_bounds__(512 + 64 * NLW, 1) void h3_gemm_lw_kernel(const H3G
   if (it + 1 < nit) step(std::integral_constant<int, 1>{});
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ping-pong form: units of 256 (M) x 128 (N), eight MFMA waves as 4 (M) x 2 (N) with a 64 x 64 wave tile (8 fragment reads
+// per 12 MFMAs) in TWO GROUPS of four (one wave of each group per SIMD) that run half a K-step apart: while group 0 issues
+// the 12 MFMAs of a k16 half-step, group 1 reads its fragments for the next one, and the other way round, a barrier
+// between the phases -- so a SIMD's matrix pipe always has one wave's MFMAs and the fragment-read latency of the other wave
+// is under them.  Four loader waves issue the direct-to-LDS loads (48 pieces of 1 KiB per K-step, three stages of 48 KB).
+// Barrier B_t closes slot t - 1.  Group 0: reads of (K-step s, half j) in slot 4 s + 2 j, MFMAs in the slot after; group 1
+// one slot later.  Loader: the batch of K-step s + 2 (stage (s + 2) % 3, last read in K-step s - 1, whose reads both groups
+// have waited for by the start of slot 4 s) in slots 4 s + 1 .. 4 s + 3, then vmcnt(12): K-step s + 1's batch has landed
+// before B_{4 s + 4}, and group 0 first reads it in slot 4 s + 4.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef PP_NOBAR
+#define PP_BARRIER() do {} while (0)
+#else
+#define PP_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+__global__ __launch_bounds__(768, 1) void h3_gemm_pp_kernel(const H3Gemm p) {
+  constexpr int TBM = 256, TBN = 128, SA = TBM * 32, SB = TBN * 32, STG = SA + SB;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
+  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  const int nk = p.K / BK;
+  const int nit = my_units * nk;
+  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) __attribute__((always_inline)) {
+    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
+    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.K * 4ull;
+    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.K * 4ull;
+    m = (unsigned long long)p.M +
+        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
+  };
+  if (wave >= 8) {
+    const int lw = wave - 8;
+    unsigned offa[8], offb[4];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int P = (lw * 8 + q) * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      offa[q] = (unsigned)(((2 * S + (c16 >> 3)) * p.K + (c16 & 7) * 4) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int P = (lw * 4 + q) * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      offb[q] = (unsigned)(((2 * S + (c16 >> 3)) * p.K + (c16 & 7) * 4) * 4);
+    }
+    const unsigned ldsA = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)(lw * 8) * 1024u;
+    const unsigned ldsB = (unsigned)(size_t)(lds_ptr_t)smem + SA * 4 + (unsigned)(lw * 4) * 1024u;
+    auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+      unsigned m0_saved;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    };
+    int l_u = L, l_k0 = 0, lst = 0;
+    unsigned long long pa, pb, pm;
+    bases(l_u, pa, pb, pm);
+    auto part = [&](int which) __attribute__((always_inline)) {
+      const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const unsigned so = (unsigned)lst * (STG * 4);
+#ifdef PP_NODMA
+      if (p.K == 12345) {
+#endif
+      if (which == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) dma(a_rsrc, ldsA + so + q * 1024, offa[q], l_k0 * 4);
+      } else if (which == 1) {
+#pragma unroll
+        for (int q = 4; q < 8; q++) dma(a_rsrc, ldsA + so + q * 1024, offa[q], l_k0 * 4);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) dma(b_rsrc, ldsB + so + q * 1024, offb[q], l_k0 * 4);
+      }
+#ifdef PP_NODMA
+      }
+#endif
+      if (which == 2) {
+        l_k0 += BK;
+        lst = lst == 2 ? 0 : lst + 1;
+        if (l_k0 == p.K) {
+          l_k0 = 0;
+          if (l_u + G < NU) l_u += G;
+          bases(l_u, pa, pb, pm);
+        }
+      }
+    };
+    part(0); part(1); part(2);
+    if (nit > 1) { part(0); part(1); part(2); }
+    if (nit > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();                          // B_0
+#pragma unroll 1
+    for (int s = 0; s < nit; s++) {
+      const bool more = s + 2 < nit;
+      PP_BARRIER();
+      if (more) part(0);
+      PP_BARRIER();
+      if (more) part(1);
+      PP_BARRIER();
+      if (more) {
+        part(2);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      PP_BARRIER();
+    }
+    PP_BARRIER();
+    return;
+  }
+  const int grp = wave >> 2, wm = wave & 3, wn = grp;
+#ifdef PP_CLOCK
+  const unsigned long long pp_t0 = __builtin_readcyclecounter(), pp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  int ahi[2], alo[2], bhi[2], blo[2];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 64 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = 4 * j + 2 * h;
+      ahi[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | c) ^ ((Ra >> 1) & 15)) << 2);
+      alo[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (c + 1)) ^ ((Ra >> 1) & 15)) << 2);
+      bhi[j] = SA + (Rb >> 1) * 64 + (((((Rb & 1) << 3) | c) ^ ((Rb >> 1) & 15)) << 2);
+      blo[j] = SA + (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (c + 1)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+  int kc = 0, c_u = L;
+  // A operand first: a lane ends with column n = lane & 31 of rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5): one store
+  // instruction writes two full 128-byte lines
+  const unsigned moff = (unsigned)((wm * 64 + 4 * (lane >> 5)) * p.N + wn * 64 + (lane & 31));
+  const float unscale = p.unscale;
+  auto flush = [&]() __attribute__((always_inline)) {
+    unsigned long long ua, ub, pm;
+    bases(c_u, ua, ub, pm);
+    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+#ifdef ABL_NOSTORE
+          if (acc[mt][nt][r] == 12345.f)
+#endif
+          dst[(mt * 32 + (r & 3) + 8 * (r >> 2)) * p.N + nt * 32] = acc[mt][nt][r] * unscale;
+          acc[mt][nt][r] = 0.f;
+        }
+    kc = 0;
+    c_u += G;
+  };
+  f16x8 ah[2], al[2], bh[2], bl[2];
+#ifdef PP_FRAGONCE
+  bool first_frag = true;
+#endif
+  auto frag = [&](int stage, int j) __attribute__((always_inline)) {
+    const float* sb = smem + stage * STG;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      ah[t] = *(const f16x8*)(sb + ahi[j] + 1024 * t);
+      al[t] = *(const f16x8*)(sb + alo[j] + 1024 * t);
+      bh[t] = *(const f16x8*)(sb + bhi[j] + 1024 * t);
+      bl[t] = *(const f16x8*)(sb + blo[j] + 1024 * t);
+    }
+  };
+  auto mfma12 = [&]() __attribute__((always_inline)) {
+#ifdef PP_M16
+    // timing experiment: the same FLOPs as 48 v_mfma_f32_16x16x32_f16 (16 accumulators of 4 registers); results meaningless
+    f32x4* a4 = (f32x4*)&acc[0][0];
+#pragma unroll
+    for (int rep = 0; rep < 3; rep++)
+#pragma unroll
+      for (int t = 0; t < 16; t++)
+        a4[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rep == 1 ? al[t & 1] : ah[t & 1], rep == 0 ? bl[(t >> 1) & 1] : bh[(t >> 1) & 1], a4[t], 0, 0, 0);
+    return;
+#endif
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+  };
+  auto half = [&](int stage, int j) __attribute__((always_inline)) {
+#ifdef PP_NOFRAG
+    if (p.K == 12345)
+#endif
+#ifdef PP_FRAGONCE
+    if (first_frag)
+#endif
+    frag(stage, j);
+#ifdef PP_FRAGONCE
+    first_frag = false;
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    PP_BARRIER();
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mfma12();
+#ifdef PP_DOUBLE
+    mfma12();
+#endif
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto step = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value;
+    half(st, 0);
+    PP_BARRIER();
+    half(st, 1);
+    if (++kc == nk) flush();
+    PP_BARRIER();
+  };
+  PP_BARRIER();                            // B_0
+  if (grp == 1) PP_BARRIER();              // group 1 runs one slot behind
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+  if (grp == 0) PP_BARRIER();
+#ifdef PP_CLOCK
+  if (blockIdx.x == 0 && tid == 0) {
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    p.clk[0] = (float)(t1 - pp_t0);
+    p.clk[1] = (float)(r1 - pp_r0);
+  }
+#endif
+}
+
+__global__ __launch_bounds__(768, 1) void h3_gemm_pp2_kernel(const H3Gemm p) {
+  constexpr int TBM = 256, TBN = 128, SA = TBM * 32, SB = TBN * 32, STG = SA + SB;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
+  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
+  const int chunk = G >> 3;
+  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (L >= NU) return;
+  const int my_units = (NU - L + G - 1) / G;
+  const int nk = p.K / BK;
+  const int nit = my_units * nk;
+  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) __attribute__((always_inline)) {
+    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
+    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.K * 4ull;
+    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.K * 4ull;
+    m = (unsigned long long)p.M +
+        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
+  };
+  if (wave >= 8) {
+    const int lw = wave - 8;
+    unsigned offa[8], offb[4];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int P = (lw * 8 + q) * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      offa[q] = (unsigned)(((2 * S + (c16 >> 3)) * p.K + (c16 & 7) * 4) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int P = (lw * 4 + q) * 64 + lane, S = P >> 4, c16 = (P & 15) ^ (S & 15);
+      offb[q] = (unsigned)(((2 * S + (c16 >> 3)) * p.K + (c16 & 7) * 4) * 4);
+    }
+    const unsigned ldsA = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)(lw * 8) * 1024u;
+    const unsigned ldsB = (unsigned)(size_t)(lds_ptr_t)smem + SA * 4 + (unsigned)(lw * 4) * 1024u;
+    auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
+      unsigned m0_saved;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    };
+    int l_u = L, l_k0 = 0, lst = 0;
+    unsigned long long pa, pb, pm;
+    bases(l_u, pa, pb, pm);
+    auto part = [&](int which) __attribute__((always_inline)) {
+      const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
+      const unsigned so = (unsigned)lst * (STG * 4);
+      if (which == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) dma(a_rsrc, ldsA + so + q * 1024, offa[q], l_k0 * 4);
+      } else {
+#pragma unroll
+        for (int q = 6; q < 8; q++) dma(a_rsrc, ldsA + so + q * 1024, offa[q], l_k0 * 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) dma(b_rsrc, ldsB + so + q * 1024, offb[q], l_k0 * 4);
+        l_k0 += BK;
+        lst = lst == 2 ? 0 : lst + 1;
+        if (l_k0 == p.K) {
+          l_k0 = 0;
+          if (l_u + G < NU) l_u += G;
+          bases(l_u, pa, pb, pm);
+        }
+      }
+    };
+    // prologue: batches 0 and 1 whole; batch 0 has landed before B_0.  Every MFMA wave waits for its fragment reads BEFORE
+    // the barrier that ends its read slot, so buffer b % 3 is free once B_{2 b + 2} has passed (group 1 reads K-step b in slot
+    // 2 b + 1): batch b + 3 may go out from slot 2 b + 2 = 2 (b + 3) - 4 on.  Batch s + 2: first half in slot 2 s, second half
+    // in slot 2 s + 1, and then vmcnt(12): batch s + 1 has landed before B_{2 s + 2}; group 0 reads it in slot 2 s + 2.
+    part(0); part(1);
+    if (nit > 1) { part(0); part(1); }
+    if (nit > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();                          // B_0
+#pragma unroll 1
+    for (int s = 0; s < nit; s++) {
+      const bool more = s + 2 < nit;
+      if (more) part(0);
+      PP_BARRIER();
+      if (more) {
+        part(1);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      PP_BARRIER();
+    }
+    PP_BARRIER();
+    return;
+  }
+  const int grp = wave >> 2, wm = wave & 3, wn = grp;
+#ifdef PP_CLOCK
+  const unsigned long long pp_t0 = __builtin_readcyclecounter(), pp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  int ahi[2], alo[2], bhi[2], blo[2];
+  {
+    const int Ra = wm * 64 + (lane & 31), Rb = wn * 64 + (lane & 31), h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int c = 4 * j + 2 * h;
+      ahi[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | c) ^ ((Ra >> 1) & 15)) << 2);
+      alo[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (c + 1)) ^ ((Ra >> 1) & 15)) << 2);
+      bhi[j] = SA + (Rb >> 1) * 64 + (((((Rb & 1) << 3) | c) ^ ((Rb >> 1) & 15)) << 2);
+      blo[j] = SA + (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (c + 1)) ^ ((Rb >> 1) & 15)) << 2);
+    }
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+  int kc = 0, c_u = L;
+  // A operand first: a lane ends with column n = lane & 31 of rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5): one store
+  // instruction writes two full 128-byte lines
+  const unsigned moff = (unsigned)((wm * 64 + 4 * (lane >> 5)) * p.N + wn * 64 + (lane & 31));
+  const float unscale = p.unscale;
+  auto flush = [&]() __attribute__((always_inline)) {
+    unsigned long long ua, ub, pm;
+    bases(c_u, ua, ub, pm);
+    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+#ifdef ABL_NOSTORE
+          if (acc[mt][nt][r] == 12345.f)
+#endif
+          dst[(mt * 32 + (r & 3) + 8 * (r >> 2)) * p.N + nt * 32] = acc[mt][nt][r] * unscale;
+          acc[mt][nt][r] = 0.f;
+        }
+    kc = 0;
+    c_u += G;
+  };
+  f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+  auto frag = [&](int stage, int j) __attribute__((always_inline)) {
+    const float* sb = smem + stage * STG;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      ah[j][t] = *(const f16x8*)(sb + ahi[j] + 1024 * t);
+      al[j][t] = *(const f16x8*)(sb + alo[j] + 1024 * t);
+      bh[j][t] = *(const f16x8*)(sb + bhi[j] + 1024 * t);
+      bl[j][t] = *(const f16x8*)(sb + blo[j] + 1024 * t);
+    }
+  };
+  auto mfma12 = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j][mt], bl[j][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j][mt], bh[j][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j][mt], bh[j][nt], acc[mt][nt], 0, 0, 0);
+  };
+  auto step = [&](auto ST) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value;
+#ifdef PP_NOFRAG
+    if (p.K == 12345)
+#endif
+    {
+      frag(st, 0);
+      frag(st, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only: the stage is in registers before the barrier (see the loader)
+    PP_BARRIER();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mfma12(0);
+    mfma12(1);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++kc == nk) flush();
+    PP_BARRIER();
+  };
+  PP_BARRIER();                            // B_0
+  if (grp == 1) PP_BARRIER();              // group 1 runs one slot behind
+  int it = 0;
+#pragma unroll 1
+  for (; it + 3 <= nit; it += 3) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
+  if (it < nit) step(std::integral_constant<int, 0>{});
+  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
+  if (grp == 0) PP_BARRIER();
+#ifdef PP_CLOCK
+  if (blockIdx.x == 0 && tid == 0) {
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    p.clk[0] = (float)(t1 - pp_t0);
+    p.clk[1] = (float)(r1 - pp_r0);
+  }
+#endif
+}
+
+static float run_pp(const H3Gemm& p, int iters, int which = 1) {
+  if (p.ntile_pad % 256 || p.N % 128) return -1.f;
+  auto k = which == 2 ? h3_gemm_pp2_kernel : h3_gemm_pp_kernel;
+  const int units = p.ncomp * (p.ntile_pad / 256) * (p.N / 128);
+  const int g = units < 256 ? 8 * ((units + 7) / 8) : 256;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k, dim3(g), dim3(768), 0, 0, p);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k, dim3(g), dim3(768), 0, 0, p);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters;
+}
+
 template <int NLW>
 static float run_lw(const H3Gemm& p, int iters) {
   auto k = h3_gemm_lw_kernel<NLW>;
@@ -475,10 +946,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpy((char*)dV + c * vb, As.data(), vb, hipMemcpyHostToDevice));
     CK(hipMemcpy((char*)dU + c * ub, Bs.data(), ub, hipMemcpyHostToDevice));
   }
-  H3Gemm p{dV, dU, dM, M, N, K, ncomp, 1.f / (sa * sb)};
+  float* dClk;
+  CK(hipMalloc((void**)&dClk, 64));
+  H3Gemm p{dV, dU, dM, M, N, K, ncomp, 1.f / (sa * sb), dClk};
   const int shape = argc > 6 ? atoi(argv[6]) : 0;
   float ms = shape == 1 ? run_shape<2, 2, 4, 2>(p, iters) : shape == 2 ? run_shape<2, 2, 2, 4>(p, iters)
-           : shape == 3 ? run_shape<4, 1, 2, 4>(p, iters) : shape == 12 ? run_lw<2>(p, iters) : shape == 14 ? run_lw<4>(p, iters)
+           : shape == 3 ? run_shape<4, 1, 2, 4>(p, iters) : shape == 20 ? run_pp(p, iters) : shape == 21 ? run_pp(p, iters, 2) : shape == 12 ? run_lw<2>(p, iters) : shape == 14 ? run_lw<4>(p, iters)
            : run_shape<2, 1, 2, 4>(p, iters);
   if (ms < 0) { printf("shape %d does not divide M / N\n", shape); return 0; }
   const double flop = 2.0 * ncomp * M * N * K;
@@ -498,6 +971,10 @@ int main(int argc, char** argv) {
     }
   }
   rms = std::sqrt(rms / 8000);
+#ifdef PP_CLOCK
+  { float ck[2]; CK(hipMemcpy(ck, dClk, 8, hipMemcpyDeviceToHost));
+    printf("block 0: %.0f core cycles, %.0f ticks of 100 MHz -> %.3f GHz\n", ck[0], ck[1], ck[0] / ck[1] * 0.1); }
+#endif
   printf("check: max |err| %.3e (rms of C %.3g, relative %.2e)\n", worst, rms, worst / rms);
   return worst / rms < 1e-5 ? 0 : 1;
 }
