@@ -243,7 +243,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--lanes", type=int, default=4, help="independent stream/workspace lanes per GPU")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="independent stream/workspace lanes per GPU (2 since round 3: with the hidden-split recurrence in the "
+                         "pipelined path a batch alone takes 2.9 ms instead of 3.9, and two in flight fill the chip)")
     ap.add_argument("--lines", type=int, default=0,
                     help="BASELINE configs[3]: a fixed job of this many synthetic 32x280 lines (1000000 in the config), "
                          "generated on-device from --seed and sharded over the ranks; 0 = the default per-step mode")
@@ -441,6 +443,7 @@ def main():
             model2.__del__()
             del model2
 
+    split_tmo = model.split_timeouts() if plain is None else None   # (the first handle is gone when the alternatives ran)
     run = None          # same order at every exit: pinned buffers (held by the closure) go before the handle's streams
     gc.collect()
     if rank != 0:
@@ -562,7 +565,7 @@ def main():
         "config": {"workload": "configs[1]: CRNN %s, batch 256 synthetic 32x280 grayscale lines per step per GPU, "
                                "uint8 lines resident in HBM -> decoded strings on the host" % args.precision,
                    "batch": BATCH, "width": WIDTH, "nclass": NCLASS, "lines_per_step": BATCH * world,
-                   "lanes_per_gpu": NL, "gpu_max_hw_queues": _hw_queues(),
+                   "lanes_per_gpu": NL, "gpu_max_hw_queues": _hw_queues(), "split_timeouts": split_tmo,
                    "persistent_blocks": {"pipelined_launches": int(os.environ.get("CRNN_PIPELINE_BLOCKS", "192")),
                                          "alone_on_the_device (the per-kernel table and roofline)": 256},
                    "timed_region": "normalise -> conv stack -> 2x BiLSTM -> classifier arg-max -> CTC collapse on the GPU, label "

@@ -148,7 +148,8 @@ CRNN_API int crnn_predict_page(crnn_handle* h, const uint8_t* page, int32_t heig
  * width-bucketing scheduler and bench.py use): d_gray uint8 [n,32,w] device pointer; widths
  * host int32[n] (valid width of each line, <= w) or NULL when every line is w wide.
  * Outputs are DEVICE pointers: d_lab [n,T] int32, d_len [n] int32, d_raw [n,T] int32 or NULL,
- * with T = crnn_out_len(w).  Runs asynchronously unless sync != 0.  Successive calls rotate over
+ * with T = crnn_out_len(w).  Runs asynchronously unless sync != 0 (a sync call of up to 512 lines also gets the
+ * latency form of the LSTM recurrence, like the host paths: same results bit for bit).  Successive calls rotate over
  * the handle's lanes (crnn_config.lanes): the call returns the lane index (>= 0) it was queued
  * on, whose stream is crnn_stream(h, lane); work on different lanes overlaps on the device.
  * No reference counterpart (the reference never keeps data on a device). */

@@ -720,13 +720,20 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   const int M = n * g.T;
   const double recflop = 2.0 * M * 2 * 1024 * 256;
   const double recbytes = 4.0 * M * 2048 + es * ((double)M * 512 + 2 * 1024 * 256);
-  const bool split = allow_split && !b16 && h->cfg.lstm && n <= h->split_max && (double)M * 2048.0 < 2.0e9;
+  // asynchronous device path (several lanes in flight): the hidden-split form there too (round 3; CRNN_PIPE_SPLIT=0: the
+  // one-workgroup kernel), with the one-workgroup kernel queued behind it and gated on the time-out word, since nobody on
+  // the host looks at that word in this path.  Measured (bench.py, 256 lines per step): 104.8 k -> 109.3 k lines/s at 100
+  // steps and 98-101 k -> 107 k at 20 steps, with TWO lanes instead of four (a batch alone takes 2.9 instead of 3.9 ms)
+  static const bool pipe_split = !(getenv("CRNN_PIPE_SPLIT") && atoi(getenv("CRNN_PIPE_SPLIT")) == 0);
+  const bool gated = !allow_split && pipe_split && h->d_whh3[0] != nullptr;
+  const bool split = (allow_split || gated) && !b16 && h->cfg.lstm && n <= h->split_max && (double)M * 2048.0 < 2.0e9;
   unsigned* d_sync = nullptr;
   if (split) {
+    const bool fresh = tl_cur->sync.p == nullptr;
     int rc = ensure_buf(h, tl_cur->sync, 4096);
     if (rc) return rc;
-    d_sync = (unsigned*)tl_cur->sync.p;                       // [0] the time-out word
-    HIPCHK(h, hipMemsetAsync(d_sync, 0, 16, s));
+    d_sync = (unsigned*)tl_cur->sync.p;                       // [0] the time-out word, [1] repeats done on the device (gated)
+    HIPCHK(h, hipMemsetAsync(d_sync, 0, fresh ? 4096 : 4, s));
   }
   tl_cur->split_used = split;
   auto rec = [&](int l, float* out) {
@@ -739,6 +746,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       if (sh3 && h->d_whh3[l]) launch_lstm_rec_split_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], d_sync, s);
       else launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync, s);
       if (h->split_ev) (void)hipEventRecord(h->split_ev, s);
+      if (gated) launch_lstm_rec_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], s, d_sync);
     }
     else if (h->d_whh3[l]) launch_lstm_rec_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], s);
     else launch_lstm_rec(p.xp, h->d_whhp[l], out, tlen, n, g.T, s);
@@ -1552,7 +1560,19 @@ int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_
   // several lanes in flight (no sync, not the one-batch-at-a-time profiling mode): leave CUs to the other lanes' kernels
   static const int pipe_blocks = getenv("CRNN_PIPELINE_BLOCKS") ? atoi(getenv("CRNN_PIPELINE_BLOCKS")) : 192;
   tl_cur->pblocks = (!sync && !h->kprof && h->nlanes > 1) ? pipe_blocks : 256;
-  if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
+  // sync callers have nothing else in flight on this lane and wait for the result: they get the latency form of the
+  // recurrence (four workgroups per group, W_hh resident; 0.45 instead of 0.78 ms per layer at 256 lines), with the same
+  // give-up-and-repeat handling as the host paths
+  if ((rc = run_network(h, g, p, widths, d_lab, d_len, false, sync != 0))) return rc;
+  if (sync && tl_cur->split_used) {
+    unsigned tmo = 0;
+    HIPCHK(h, hipMemcpyAsync(&tmo, tl_cur->sync.p, 4, hipMemcpyDeviceToHost, tl_cur->stream));
+    HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
+    if (tmo) {
+      h->split_timeouts++;
+      if ((rc = run_network(h, g, p, widths, d_lab, d_len, false, false))) return rc;
+    }
+  }
   if (d_raw)
     HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, tl_cur->stream));
   if (sync) HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
@@ -1686,7 +1706,22 @@ int crnn_next_lane(crnn_handle* h) {
   return h->next_lane;
 }
 
-int64_t crnn_split_timeouts(const crnn_handle* h) { return h ? h->split_timeouts.load() : 0; }
+int64_t crnn_split_timeouts(const crnn_handle* h) {
+  if (!h) return 0;
+  int64_t n = h->split_timeouts.load();
+  // repeats that the asynchronous device path did by itself (the gated one-workgroup kernel counts them in the lane's
+  // sync buffer); read without locks: a diagnostic, exact once the lanes are idle
+  if (!h->dev_ready || h->dev_pid != getpid()) return n;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(h->cfg.device) != hipSuccess) return n;
+  for (int l = 0; l < h->nlanes; l++) {
+    const unsigned* d = (const unsigned*)h->lanes[l].sync.p;
+    unsigned c = 0;
+    if (d && hipMemcpy(&c, d + 1, 4, hipMemcpyDeviceToHost) == hipSuccess) n += c;
+  }
+  if (cur >= 0) (void)hipSetDevice(cur);
+  return n;
+}
 
 int crnn_last_timing(crnn_handle* h, float ms[5]) {
   if (!h || !ms) return CRNN_ERR_ARG;

@@ -267,7 +267,7 @@ void launch_lstm_rec_split_h3(const float* xp, const void* whh3, float* rec, con
                               float unscale, unsigned* tmo, hipStream_t s);
 // f16x3 form of the recurrence (crnn_kernels.hip): whh3 from pack_whh_h3 (2 * 1024 * 256 * 2 halves), unscale its return value
 void launch_lstm_rec_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T, float unscale,
-                        hipStream_t s);
+                        hipStream_t s, const unsigned* gate = nullptr);
 float pack_whh_h3(const float* whh_fwd, const float* whh_rev, uint16_t* packed);
 // host-side repack of W_hh [2][1024][256] into the per-lane fragment order the kernel streams.
 void pack_whh(const float* whh_fwd, const float* whh_rev, float* packed /* 2*1024*256 */);

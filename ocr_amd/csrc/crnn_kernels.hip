@@ -3108,10 +3108,23 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------
 typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
 constexpr int HLS = 1040;
+// RES (round 3; CRNN_REC_RES=0 keeps the streaming form): a quarter of W_hh stays on the CU for the whole launch -- the
+// wave's 32 fragments of k-step 7 in registers (128 VGPRs; 1 wave per SIMD, so the file is there) and its 32 fragments of
+// k-step 6 in LDS (32 KiB per wave; h is then single-buffered, one more barrier per step, to make room: 16.6 + 128 KiB) --
+// so a step streams 768 KiB instead of 1 MiB from L2, and the first fragments of the next step are fetched two k-steps
+// earlier.  The MFMA sequence of every accumulator is unchanged (k-steps ascending; lo hi, hi lo, hi hi inside one), so the
+// results are bit-identical to the streaming form and to lstm_rec_split_h3_kernel.
+template <bool RES>
 __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restrict__ xp, const uint4* __restrict__ whh3,
                                                           float* __restrict__ rec, const int32_t* __restrict__ tlen,
-                                                          int B, int T, float unscale) {
-  __shared__ __attribute__((aligned(16))) unsigned char hs[2 * LB * HLS];
+                                                          int B, int T, float unscale, const unsigned* __restrict__ gate) {
+  // gate != nullptr: run only if *gate != 0 (the repeat of a hidden-split launch that gave up, queued behind it by callers
+  // that cannot look at the time-out word themselves: the asynchronous device path)
+  if (gate && __builtin_nontemporal_load(gate) == 0u) return;
+  if (gate && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd((unsigned*)gate + 1, 1u);   // counted (crnn_split_timeouts)
+  constexpr int NHB = RES ? 1 : 2;                       // h images
+  constexpr int WL = RES ? 4 * 32 * 1024 : 0;            // bytes of LDS-resident fragments
+  __shared__ __attribute__((aligned(16))) unsigned char hs[NHB * LB * HLS + WL];
   const int dir = blockIdx.y, b0 = blockIdx.x * LB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
   const int b = b0 + bl;
@@ -3122,7 +3135,7 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
     const int tj = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
     Tmax = tj > Tmax ? tj : Tmax;
   }
-  for (int i = tid; i < 2 * LB * HLS / 4; i += 256) ((unsigned*)hs)[i] = 0u;
+  for (int i = tid; i < NHB * LB * HLS / 4; i += 256) ((unsigned*)hs)[i] = 0u;
   float c[4][4], h[4][4];
 #pragma unroll
   for (int u = 0; u < 4; u++)
@@ -3131,6 +3144,17 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
   // fragment (ks, tile, part) of this wave at wp[((ks * 16 + tile) * 2 + part) * 64]
   const uint4* wp = whh3 + ((size_t)(dir * 4 + wave) * 8 * 16 * 2) * 64 + lane;
   uint4 wa[8][2], wb[8][2];
+  uint4 wr[RES ? 16 : 1][2];                             // k-step 7, resident
+  uint4* wl = (uint4*)(hs + NHB * LB * HLS) + wave * (32 * 64) + lane;   // k-step 6 in LDS: fragment f at wl[f * 64]
+  if (RES) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      wr[t][0] = wp[(size_t)((7 * 16 + t) * 2) * 64];
+      wr[t][1] = wp[(size_t)((7 * 16 + t) * 2 + 1) * 64];
+    }
+#pragma unroll
+    for (int f = 0; f < 32; f++) wl[f * 64] = wp[(size_t)(6 * 16 * 2 + f) * 64];
+  }
 #pragma unroll
   for (int t = 0; t < 8; t++) { wa[t][0] = wp[(size_t)(t * 2) * 64]; wa[t][1] = wp[(size_t)(t * 2 + 1) * 64]; }
   __syncthreads();
@@ -3151,7 +3175,7 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
     f32x4 acc[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned char* hrow = hs + cur * LB * HLS + bl * HLS + q * 256;
+    const unsigned char* hrow = hs + (RES ? 0 : cur) * LB * HLS + bl * HLS + q * 256;
     auto mfma8 = [&](const uint4 (&w)[8][2], int t0, f16x8r hh, f16x8r hl) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < 8; i++)
@@ -3163,8 +3187,9 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
       for (int i = 0; i < 8; i++)
         acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[i][0]), hh, acc[t0 + i], 0, 0, 0);
     };
+    constexpr int NKS = RES ? 6 : 8;                     // streamed k-steps
 #pragma unroll 1
-    for (int ks = 0; ks < 8; ks++) {
+    for (int ks = 0; ks < NKS; ks++) {
       const f16x8r hh = *(const f16x8r*)(hrow + ks * 32), hl = *(const f16x8r*)(hrow + ks * 32 + 16);
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -3172,7 +3197,8 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
         wb[i][1] = wp[(size_t)((ks * 16 + 8 + i) * 2 + 1) * 64];
       }
       mfma8(wa, 0, hh, hl);
-      const int kn = (ks + 1) & 7;      // the last refill wraps to k-step 0 of the NEXT step: it lands under the gate math
+      // the last refill wraps to k-step 0 of the NEXT step: it lands under the resident k-steps / the gate math
+      const int kn = ks + 1 == NKS ? 0 : ks + 1;
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         wa[i][0] = wp[(size_t)((kn * 16 + i) * 2) * 64];
@@ -3180,7 +3206,40 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
       }
       mfma8(wb, 8, hh, hl);
     }
-    unsigned char* hn = hs + (cur ^ 1) * LB * HLS + bl * HLS;
+    if (RES) {
+      // k-step 6 from LDS (eight tiles at a time through the set the loop has just freed), k-step 7 from registers; every
+      // accumulator still sees k-step 6 before k-step 7.  The reads of a half are issued as one block (the compiler would
+      // otherwise wait for each before its MFMA), and the second half's are in flight under the first half's k-step 7.
+      const f16x8r hh6 = *(const f16x8r*)(hrow + 6 * 32), hl6 = *(const f16x8r*)(hrow + 6 * 32 + 16);
+      f16x8r hh7, hl7;
+      auto mfma7 = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, wr[t0 + i][1]), hh7, acc[t0 + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, wr[t0 + i][0]), hl7, acc[t0 + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, wr[t0 + i][0]), hh7, acc[t0 + i], 0, 0, 0);
+      };
+#pragma unroll
+      for (int i = 0; i < 8; i++) { wb[i][0] = wl[(i * 2) * 64]; wb[i][1] = wl[(i * 2 + 1) * 64]; }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(wb, 0, hh6, hl6);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; i++) { wb[i][0] = wl[((8 + i) * 2) * 64]; wb[i][1] = wl[((8 + i) * 2 + 1) * 64]; }
+      hh7 = *(const f16x8r*)(hrow + 7 * 32);
+      hl7 = *(const f16x8r*)(hrow + 7 * 32 + 16);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma7(0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(wb, 8, hh6, hl6);
+      mfma7(8);
+      __syncthreads();     // single h image: every wave has read it before anybody writes the next one
+    }
+    unsigned char* hn = hs + (RES ? 0 : (cur ^ 1)) * LB * HLS + bl * HLS;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       f32x4 hv4;
@@ -3218,9 +3277,14 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
 }
 
 void launch_lstm_rec_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T, float unscale,
-                        hipStream_t s) {
-  hipLaunchKernelGGL(lstm_rec_h3_kernel, dim3((B + LB - 1) / LB, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen, B, T,
-                     unscale);
+                        hipStream_t s, const unsigned* gate) {
+  static const bool res = !(getenv("CRNN_REC_RES") && atoi(getenv("CRNN_REC_RES")) == 0);
+  if (res)
+    hipLaunchKernelGGL(lstm_rec_h3_kernel<true>, dim3((B + LB - 1) / LB, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen,
+                       B, T, unscale, gate);
+  else
+    hipLaunchKernelGGL(lstm_rec_h3_kernel<false>, dim3((B + LB - 1) / LB, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen,
+                       B, T, unscale, gate);
 }
 
 // W_hh [2][1024][256] -> the fragment order lstm_rec_h3_kernel streams, as (hi, lo) fp16 with ONE power-of-two scale;
