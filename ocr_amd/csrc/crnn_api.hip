@@ -43,6 +43,15 @@ struct DevBuf {
 // own address) and only that pointer is ever handed to kernels, memsets or copies.
 static __device__ __align__(256) unsigned char scratch[CRNN_NOALLOC_SCRATCH_BYTES];
 constexpr int MAX_DEVICES = 64;
+// Hidden-split recurrence launches are chained per device and process: each waits for the previous one's event, so that two
+// of them -- of different lanes or of different handles -- are never both partly resident and spinning for workgroups that
+// cannot be placed (that would only end by their time-outs).  The event belongs to the process that created it (fork).
+struct SplitChain {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  pid_t pid = 0;
+};
+SplitChain g_split[MAX_DEVICES];
 void* g_scratch_ptr[MAX_DEVICES] = {};      // [device ordinal] -> device address of `scratch` on that GPU (this process)
 pid_t g_scratch_pid[MAX_DEVICES] = {};
 std::mutex g_scratch_mu;
@@ -122,10 +131,8 @@ struct crnn_handle {
   // at 512 lines -- all of them must be resident at once) use the hidden-split latency kernel in the synchronous host
   // paths (CRNN_LSTM_SPLIT=<max lines>, 0 = never); measured faster than the one-workgroup kernel up to 1024 lines
   int split_max = 512;
-  // at most one hidden-split kernel runs at a time (each waits for the previous one's event): two of them, each
-  // partly resident and spinning for workgroups that cannot be placed, would only end by their time-outs
-  std::mutex split_mu;
-  hipEvent_t split_ev = nullptr;
+  // (at most one hidden-split kernel runs on a DEVICE at a time, whichever handle of this process launched it:
+  // g_split below)
   std::atomic<int64_t> split_timeouts{0};   // batches repeated because the hidden-split recurrence gave up (crnn_split_timeouts)
   bool wino_fused = true;   // GEMM + output transform in one kernel (CRNN_WINO_FUSED=0: separate kernels)
   // Load-time channel equalisation (equalize_channels below; CRNN_EQUALIZE=0: off): the power-of-two factor that
@@ -247,7 +254,6 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     // belong to its context -- drop them, do not free)
     h->dev_ready = false;
     h->weights_on_dev = false;
-    h->split_ev = nullptr;
     h->scratch_ptr = nullptr;
     for (Lane& L : h->lanes) {
       L.ev_valid = false;
@@ -739,13 +745,15 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   auto rec = [&](int l, float* out) {
     if (b16) launch_lstm_rec_bf16(p.xp, h->db_whhp[l], out, tlen, n, g.T, s);
     else if (split) {
-      std::lock_guard<std::mutex> lk(h->split_mu);
-      if (!h->split_ev) (void)hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming);
-      if (h->split_ev) (void)hipStreamWaitEvent(s, h->split_ev, 0);
+      SplitChain& ch = g_split[h->cfg.device >= 0 && h->cfg.device < MAX_DEVICES ? h->cfg.device : 0];
+      std::lock_guard<std::mutex> lk(ch.mu);
+      if (ch.pid != getpid()) { ch.ev = nullptr; ch.pid = getpid(); }     // a forked child starts its own chain
+      if (!ch.ev) (void)hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming);
+      if (ch.ev) (void)hipStreamWaitEvent(s, ch.ev, 0);
       static const bool sh3 = !(getenv("CRNN_SPLIT_H3") && atoi(getenv("CRNN_SPLIT_H3")) == 0);
       if (sh3 && h->d_whh3[l]) launch_lstm_rec_split_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], d_sync, s);
       else launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync, s);
-      if (h->split_ev) (void)hipEventRecord(h->split_ev, s);
+      if (ch.ev) (void)hipEventRecord(ch.ev, s);
       if (gated) launch_lstm_rec_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], s, d_sync);
     }
     else if (h->d_whh3[l]) launch_lstm_rec_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], s);
@@ -1783,7 +1791,6 @@ void crnn_destroy(crnn_handle* h) {
     (void)hipFree(h->d_cls_wnorm);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }
-    if (h->split_ev) (void)hipEventDestroy(h->split_ev);
     for (int l = 0; l < h->nlanes; l++) {
       Lane& L = h->lanes[l];
       (void)hipFree(L.arena.p); (void)hipFree(L.pre.p); (void)hipFree(L.io.p); (void)hipHostFree(L.stage.p);

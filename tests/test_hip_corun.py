@@ -31,3 +31,13 @@ def test_conv0_win4_beside_mfma_kernels(aggressor):
     assert os.path.exists(TOOL), "tools/corun_test missing: make -C ocr_amd/csrc"
     r = subprocess.run([TOOL, str(aggressor), "3000"], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0 and " 0 of 3000 iterations differ" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aggressor", [1, 14])
+def test_cls_select_beside_mfma_kernels(aggressor):
+    """The other kernel that was moved to crnn_kernels_nopk.hip: the classifier's candidate selection and exact fp32 scoring
+    (cls_select_kernel, fp16 logits) as the victim -- its arg-max indices on 2048 rows must not change beside the MFMA kernels."""
+    assert os.path.exists(TOOL), "tools/corun_test missing: make -C ocr_amd/csrc"
+    r = subprocess.run([TOOL, str(aggressor), "1500", "256", "2"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0 and " 0 of 1500 iterations differ" in r.stdout, r.stdout + r.stderr

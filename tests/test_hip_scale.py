@@ -348,6 +348,54 @@ def test_split_recurrences_of_concurrent_callers(golden, synth_en):
 
 
 @pytest.mark.gpu
+def test_split_recurrences_of_two_handles_on_one_gpu(synth_en):
+    """Two handles on the one GPU (two model objects in one process), a thread each, both using the hidden-split recurrence
+    -- host batches and pipelined device batches: the split launches are chained per DEVICE, not per handle, so they
+    cannot end up half resident and spinning for each other.  Results must equal the single-threaded ones; the number of
+    repeats with the one-workgroup kernel (crnn_split_timeouts, device-side repeats included) is reported and must be 0."""
+    import torch
+    from ocr_amd.crnn.network_hip import CRNN
+    ms = []
+    for _ in range(2):
+        m = CRNN(32, 1, 65, 256, alphabet=keys.alphabetEnglish, device=0, lanes=2)
+        m.load_state_dict(synth_en)
+        ms.append(m)
+    rs = np.random.RandomState(13)
+    jobs = [[rs.randint(0, 256, size=(32, int(w))).astype(np.uint8) for w in rs.randint(40, 400, size=n)] for n in (30, 70)]
+    batches = [rs.randint(0, 256, size=(96, 32, 200)).astype(np.uint8) for _ in range(2)]
+    want_host = [ms[k].predict_lines(jobs[k], min_cols=1 << 30) for k in range(2)]
+    want_dev = [_device_batch(ms[k], batches[k]) for k in range(2)]
+    errs = []
+
+    def work(k):
+        try:
+            dev = torch.device("cuda", 0)
+            d = torch.from_numpy(batches[k]).to(dev)
+            n, _, w = batches[k].shape
+            T = w // 4 + 1
+            outs = [(torch.zeros((n, T), dtype=torch.int32, device=dev), torch.zeros((n, T), dtype=torch.int32, device=dev),
+                     torch.zeros((n,), dtype=torch.int32, device=dev)) for _ in range(4)]
+            for rep in range(5):
+                assert ms[k].predict_lines(jobs[k], min_cols=1 << 30) == want_host[k]
+                for o in outs:                       # four batches queued back to back on the two lanes (no sync)
+                    ms[k].forward_device(d.data_ptr(), n, w, o[1].data_ptr(), o[2].data_ptr(), d_raw_ptr=o[0].data_ptr())
+                ms[k].synchronize()
+                for o in outs:
+                    assert all(np.array_equal(a, b.cpu().numpy()) for a, b in zip(want_dev[k], o)), rep
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    tmo = [m.split_timeouts() for m in ms]
+    print("split time-outs of the two handles:", tmo)
+    assert tmo == [0, 0]
+
+
+@pytest.mark.gpu
 def test_sharded_recognition_with_the_real_recogniser(synth_en, oracle_en):
     """ocr_amd/crnn/parallel.py with CRNN.predict_lines as the recogniser: rank 0 and rank 1 of a world of two, each
     with its own handle on the one GPU of this box, recognise their shards; the merged result is the oracle's strings

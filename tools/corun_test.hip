@@ -165,7 +165,7 @@ int main(int argc, char** argv) {
   const int aggr = argc > 1 ? atoi(argv[1]) : 1;
   const int iters = argc > 2 ? atoi(argv[2]) : 5000;
   const int W = argc > 3 ? atoi(argv[3]) : 256;
-  const int unfused = argc > 4 ? atoi(argv[4]) : 0;   // 1: victim = conv0_pool_kernel + wino4_in_h3_kernel
+  const int unfused = argc > 4 ? atoi(argv[4]) : 0;   // 1: victim = conv0_pool_kernel + wino4_in_h3_kernel; 2: cls_select_kernel (fp16)
   if (getenv("CORUN_PK")) {   // micro-victim mode: tools/corun_test <aggressor> <iters>   with CORUN_PK=<form>
     const int form = atoi(getenv("CORUN_PK"));
     hipStream_t s1, s2;
@@ -214,8 +214,46 @@ int main(int argc, char** argv) {
   hipMalloc(&cnt, (size_t)iters * 4);
   float* p0;
   hipMalloc(&p0, (size_t)B * 16 * W1 * 64 * 4);
+  // victim 2: the classifier's candidate selection + exact scoring (cls_select_kernel, fp16 logits: the other kernel that
+  // lives in crnn_kernels_nopk.hip) on 2048 rows of random activations; its output (the arg-max indices) goes to the
+  // first words of Vout, the rest of Vout stays zero
+  const int CM = 2048, CN = 5530, CK = 512, cldl = (CN + 7) & ~7;
+  float *cA = nullptr, *cW = nullptr, *cbias = nullptr, *canorm = nullptr, *cwnorm = nullptr;
+  uint16_t *cA16 = nullptr, *cW16 = nullptr, *cL = nullptr;
+  float cwnmax = 0.f;
+  if (unfused == 2) {
+    std::vector<float> a((size_t)CM * CK), w((size_t)CN * CK), bb(CN), wn((CN + 7) / 8 * 8, 0.f);
+    for (auto& v : a) v = ((rand() & 0xFFFF) / 32768.f - 1.f) * 0.9f;
+    for (auto& v : w) v = ((rand() & 0xFFFF) / 32768.f - 1.f) * 0.6f;
+    for (auto& v : bb) v = ((rand() & 0xFFFF) / 32768.f - 1.f) * 0.1f;
+    std::vector<uint16_t> w16(w.size());
+    for (size_t i = 0; i < w.size(); i++) w16[i] = f32_to_f16_host(w[i]);
+    for (int c = 0; c < CN; c++) {
+      double ss = 0;
+      for (int k = 0; k < CK; k++) ss += (double)w[(size_t)c * CK + k] * w[(size_t)c * CK + k];
+      wn[c] = (float)(std::sqrt(ss) * 1.000001);
+      cwnmax = std::max(cwnmax, wn[c]);
+    }
+    hipMalloc(&cA, a.size() * 4); hipMalloc(&cW, w.size() * 4); hipMalloc(&cbias, (size_t)cldl * 4); hipMalloc(&canorm, CM * 4);
+    hipMalloc(&cwnorm, wn.size() * 4); hipMalloc(&cA16, a.size() * 2); hipMalloc(&cW16, w.size() * 2);
+    hipMalloc(&cL, (size_t)CM * cldl * 2);
+    hipMemcpy(cA, a.data(), a.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(cW, w.data(), w.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(cbias, 0, (size_t)cldl * 4);
+    hipMemcpy(cbias, bb.data(), bb.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(cwnorm, wn.data(), wn.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(cW16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice);
+    launch_rows_to_bf16(cA, cA16, canorm, CM, CK, s1, 1);
+    ConvGemm cq{};
+    cq.A = (const float*)cA16; cq.Wt = (const float*)cW16; cq.bias = cbias; cq.C = (float*)cL; cq.M = CM; cq.N = CN; cq.K = CK; cq.ldc = cldl;
+    cq.Hin = cq.Win = cq.Hout = cq.Wout = 1; cq.Cin = CK; cq.ks = 1; cq.pad = 0; cq.act = 0;
+    launch_conv_gemm_bf16(cq, 2, s1);        // approximate logits, fp16, once
+    hipStreamSynchronize(s1);
+  }
   auto victim = [&](float* Vout) {
-    if (unfused) {
+    if (unfused == 2) {
+      launch_cls_select(cL, cA, cW, cbias, canorm, cwnorm, (int32_t*)Vout, CM, CN, CK, cldl, s1, 1, cwnmax);
+    } else if (unfused) {
       launch_conv0_pool(in, w9, bias, p0, nullptr, B, W, 1, s1);
       launch_wino4_in(p0, Vout, B, 16, W1, 64, s1, vs);
     } else {
