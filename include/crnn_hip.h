@@ -162,8 +162,11 @@ CRNN_API int crnn_forward_device(crnn_handle* h, const uint8_t* d_gray, int32_t 
  * threads calling crnn_forward_device on one handle the answer can be stale by the time it is used. */
 CRNN_API int crnn_next_lane(crnn_handle* h);
 
-/* crnn_forward_device for callers that must not allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, outputs and
+/* crnn_forward_device for callers that must not allocate (tight serving loops, harnesses that forbid hipMalloc, code
+ * that runs while a stream capture in global mode is active in the process: allocation calls are illegal then; the work
+ * itself is queued on the library's own stream and is NOT part of the capture; with widths != NULL the call also
+ * synchronises its stream and makes a pageable host-to-device copy, so pass widths == NULL there).
+ * It has no counterpart in the reference.  Same arguments, outputs and
  * results as crnn_forward_device, but the whole activation workspace lives in a fixed array of the code object
  * (CRNN_NOALLOC_SCRATCH_BYTES per GPU, held from module load until the process ends) and the call makes no
  * hipMalloc / hipFree / hipHostMalloc and creates no stream or event: the handle's device state and weights must

@@ -165,7 +165,7 @@ struct crnn_handle {
   uint16_t* db_whhp[2] = {};
   uint16_t* db_emb_w[2] = {};
   uint16_t* db_lin_w = nullptr;
-  bool kprof = false;
+  std::atomic<bool> kprof{false};   // (read by the timing queries without the handle mutex)
   void* scratch_ptr = nullptr;   // device address of the no-alloc workspace on cfg.device (set by ensure_device)
 
   // Lanes: independent (stream, workspace) pairs.  Successive crnn_forward_device calls go to
@@ -290,6 +290,17 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     HIPCHK(h, hipMalloc((void**)&h->d_zero_bias, 512 * sizeof(float)));
     HIPCHK(h, hipMemset(h->d_zero_bias, 0, 512 * sizeof(float)));
     HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
+    // whatever the runtime allocates lazily -- a stream's queue at its first launch, a code object at the first launch of
+    // one of its kernels -- is taken now, at set-up: crnn_forward_device_noalloc promises to take no device memory later
+    for (int l = 0; l < h->nlanes; l++) {
+      hipStream_t ls = h->lanes[l].stream;
+      launch_warm_main(ls);
+      launch_warm_bf16(ls);
+      launch_warm_nopk(ls);
+      HIPCHK(h, hipMemsetAsync(h->d_zero_bias, 0, 16, ls));
+      HIPCHK(h, hipEventRecord(h->lanes[l].ev[0], ls));
+      HIPCHK(h, hipStreamSynchronize(ls));
+    }
     h->dev_pid = getpid();
     h->dev_ready = true;
   } else {
@@ -668,7 +679,7 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
 // per-line valid widths or nullptr.  Outputs (device): plan.raw plus d_lab/d_len.
 // allow_split: the caller synchronises afterwards and checks split_timed_out() (host paths only)
 int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widths, int32_t* d_lab,
-                int32_t* d_len, bool want_logits = false, bool allow_split = false) {
+                int32_t* d_len, bool want_logits = false, bool allow_split = false, bool may_alloc = true) {
   const int n = g.n;
   const int act = h->cfg.leaky_relu ? 2 : 1;
   const int32_t *m_p0 = nullptr, *m_c1 = nullptr, *m_w2 = nullptr, *m_w3 = nullptr, *tlen = nullptr;
@@ -731,7 +742,8 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   // the host looks at that word in this path.  Measured (bench.py, 256 lines per step): 104.8 k -> 109.3 k lines/s at 100
   // steps and 98-101 k -> 107 k at 20 steps, with TWO lanes instead of four (a batch alone takes 2.9 instead of 3.9 ms)
   static const bool pipe_split = !(getenv("CRNN_PIPE_SPLIT") && atoi(getenv("CRNN_PIPE_SPLIT")) == 0);
-  const bool gated = !allow_split && pipe_split && h->d_whh3[0] != nullptr;
+  // (may_alloc == false: crnn_forward_device_noalloc -- the split form needs its sync buffer and the chain's event)
+  const bool gated = !allow_split && may_alloc && pipe_split && h->d_whh3[0] != nullptr;
   const bool split = (allow_split || gated) && !b16 && h->cfg.lstm && n <= h->split_max && (double)M * 2048.0 < 2.0e9;
   unsigned* d_sync = nullptr;
   if (split) {
@@ -1598,7 +1610,9 @@ int64_t crnn_noalloc_workspace_bytes(const crnn_handle* h, int32_t n, int32_t w)
 int crnn_forward_device_noalloc(crnn_handle* h, const uint8_t* d_gray, int32_t n, int32_t w, const int32_t* widths,
                                 int32_t* d_raw, int32_t* d_lab, int32_t* d_len, int32_t sync) {
   if (!h) return CRNN_ERR_ARG;
-  std::lock_guard<std::mutex> lk(h->mu);
+  // argument and state checks under the handle mutex; it is released before the call waits for lane 0, so that a
+  // no-alloc caller queued behind a long host-path call on lane 0 does not hold up the handle's other entry points
+  std::unique_lock<std::mutex> lk(h->mu);
   if (!d_gray || n <= 0 || w < 8 || !d_lab || !d_len) return fail(h, CRNN_ERR_ARG, "bad arguments");
   if (widths)
     for (int i = 0; i < n; i++)
@@ -1619,6 +1633,7 @@ int crnn_forward_device_noalloc(crnn_handle* h, const uint8_t* d_gray, int32_t n
              (double)CRNN_NOALLOC_SCRATCH_BYTES / 1048576.0);
     return fail(h, CRNN_ERR_ARG, msg);
   }
+  lk.unlock();
   tl_cur = &h->lanes[0];                                   // every no-alloc call is ordered on lane 0's stream
   std::lock_guard<std::mutex> lane_lk(h->lanes[0].mu);
   HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1635,7 +1650,7 @@ int crnn_forward_device_noalloc(crnn_handle* h, const uint8_t* d_gray, int32_t n
   launch_normalize(d_gray, p.x, d_w, n, w, w, s);
   kmark(h, "normalize", 0, (double)n * 32 * w * 5.0);
   int rc;
-  if ((rc = run_network(h, g, p, widths, d_lab, d_len))) return rc;
+  if ((rc = run_network(h, g, p, widths, d_lab, d_len, false, false, false))) return rc;
   if (d_raw) HIPCHK(h, hipMemcpyAsync(d_raw, p.raw, sizeof(int32_t) * (size_t)n * g.T, hipMemcpyDeviceToDevice, s));
   if (sync) HIPCHK(h, hipStreamSynchronize(s));
   return 0;
@@ -1733,8 +1748,7 @@ int64_t crnn_split_timeouts(const crnn_handle* h) {
 
 int crnn_last_timing(crnn_handle* h, float ms[5]) {
   if (!h || !ms) return CRNN_ERR_ARG;
-  std::lock_guard<std::mutex> lk(h->mu);
-  Lane& L = *h->last.load(std::memory_order_acquire);
+  Lane& L = *h->last.load(std::memory_order_acquire);      // (no handle mutex: waiting for a busy lane must not hold it)
   std::lock_guard<std::mutex> lane_lk(L.mu);
   if (!L.ev_valid) return fail(h, CRNN_ERR_STATE, "nothing has run yet");
   HIPCHK(h, hipEventSynchronize(L.ev[4]));
@@ -1754,7 +1768,6 @@ int crnn_set_profiling(crnn_handle* h, int32_t on) {
 int crnn_last_kernel_times(crnn_handle* h, int32_t cap, const char** names, float* ms, double* flops,
                            double* bytes) {
   if (!h) return CRNN_ERR_ARG;
-  std::lock_guard<std::mutex> lk(h->mu);
   Lane& L = *h->last.load(std::memory_order_acquire);
   std::lock_guard<std::mutex> lane_lk(L.mu);
   if (!h->kprof || L.nk == 0) return 0;

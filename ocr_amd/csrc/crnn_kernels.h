@@ -266,6 +266,10 @@ void launch_lstm_rec_split(const float* xp, const float* whh_packed, float* rec,
 void launch_lstm_rec_split_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T,
                               float unscale, unsigned* tmo, hipStream_t s);
 // f16x3 form of the recurrence (crnn_kernels.hip): whh3 from pack_whh_h3 (2 * 1024 * 256 * 2 halves), unscale its return value
+// empty launches, one per translation unit of kernels (device set-up: code objects loaded, stream queues created)
+void launch_warm_main(hipStream_t s);
+void launch_warm_bf16(hipStream_t s);
+void launch_warm_nopk(hipStream_t s);
 void launch_lstm_rec_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T, float unscale,
                         hipStream_t s, const unsigned* gate = nullptr);
 float pack_whh_h3(const float* whh_fwd, const float* whh_rev, uint16_t* packed);

@@ -3123,7 +3123,7 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
   if (gate && __builtin_nontemporal_load(gate) == 0u) return;
   if (gate && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd((unsigned*)gate + 1, 1u);   // counted (crnn_split_timeouts)
   constexpr int NHB = RES ? 1 : 2;                       // h images
-  constexpr int WL = RES ? 4 * 32 * 1024 : 0;            // bytes of LDS-resident fragments
+  constexpr int WL = RES ? 4 * 34 * 1024 : 0;            // bytes of LDS-resident fragments
   __shared__ __attribute__((aligned(16))) unsigned char hs[NHB * LB * HLS + WL];
   const int dir = blockIdx.y, b0 = blockIdx.x * LB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
@@ -3144,16 +3144,18 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
   // fragment (ks, tile, part) of this wave at wp[((ks * 16 + tile) * 2 + part) * 64]
   const uint4* wp = whh3 + ((size_t)(dir * 4 + wave) * 8 * 16 * 2) * 64 + lane;
   uint4 wa[8][2], wb[8][2];
-  uint4 wr[RES ? 16 : 1][2];                             // k-step 7, resident
-  uint4* wl = (uint4*)(hs + NHB * LB * HLS) + wave * (32 * 64) + lane;   // k-step 6 in LDS: fragment f at wl[f * 64]
+  uint4 wr[RES ? 15 : 1][2];                             // k-step 7, tiles 0..14, resident (tile 15: LDS)
+  uint4* wl = (uint4*)(hs + NHB * LB * HLS) + wave * (34 * 64) + lane;   // k-step 6 (+ tile 15 of k-step 7) in LDS: fragment f at wl[f * 64]
   if (RES) {
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
+    for (int t = 0; t < 15; t++) {
       wr[t][0] = wp[(size_t)((7 * 16 + t) * 2) * 64];
       wr[t][1] = wp[(size_t)((7 * 16 + t) * 2 + 1) * 64];
     }
 #pragma unroll
     for (int f = 0; f < 32; f++) wl[f * 64] = wp[(size_t)(6 * 16 * 2 + f) * 64];
+    wl[32 * 64] = wp[(size_t)((7 * 16 + 15) * 2) * 64];
+    wl[33 * 64] = wp[(size_t)((7 * 16 + 15) * 2 + 1) * 64];
   }
 #pragma unroll
   for (int t = 0; t < 8; t++) { wa[t][0] = wp[(size_t)(t * 2) * 64]; wa[t][1] = wp[(size_t)(t * 2 + 1) * 64]; }
@@ -3165,13 +3167,16 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
     const size_t rowi = (size_t)(b < B ? b : 0) * T + t;
     const float* xrow = xp + rowi * 2048 + dir * 1024 + wave * 64 + q * 4;
     f32x4 xg[4][4];
+    auto load_xg = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = 0; g < 4; g++)
+      for (int g = 0; g < 4; g++)
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        xg[g][u] = active ? *(const f32x4*)(xrow + g * 256 + u * 16) : z;
-      }
+        for (int u = 0; u < 4; u++) {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          xg[g][u] = active ? *(const f32x4*)(xrow + g * 256 + u * 16) : z;
+        }
+    };
+    load_xg();
     f32x4 acc[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -3212,16 +3217,18 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
       // otherwise wait for each before its MFMA), and the second half's are in flight under the first half's k-step 7.
       const f16x8r hh6 = *(const f16x8r*)(hrow + 6 * 32), hl6 = *(const f16x8r*)(hrow + 6 * 32 + 16);
       f16x8r hh7, hl7;
+      uint4 w15[2];          // tile 15 of k-step 7, from LDS
       auto mfma7 = [&](int t0) __attribute__((always_inline)) {
+        auto W = [&](int t, int part) __attribute__((always_inline)) { return t < 15 ? wr[t < 15 ? t : 0][part] : w15[part]; };
 #pragma unroll
         for (int i = 0; i < 8; i++)
-          acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, wr[t0 + i][1]), hh7, acc[t0 + i], 0, 0, 0);
+          acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, W(t0 + i, 1)), hh7, acc[t0 + i], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 8; i++)
-          acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, wr[t0 + i][0]), hl7, acc[t0 + i], 0, 0, 0);
+          acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, W(t0 + i, 0)), hl7, acc[t0 + i], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 8; i++)
-          acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, wr[t0 + i][0]), hh7, acc[t0 + i], 0, 0, 0);
+          acc[t0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, W(t0 + i, 0)), hh7, acc[t0 + i], 0, 0, 0);
       };
 #pragma unroll
       for (int i = 0; i < 8; i++) { wb[i][0] = wl[(i * 2) * 64]; wb[i][1] = wl[(i * 2 + 1) * 64]; }
@@ -3232,6 +3239,8 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
       for (int i = 0; i < 8; i++) { wb[i][0] = wl[((8 + i) * 2) * 64]; wb[i][1] = wl[((8 + i) * 2 + 1) * 64]; }
       hh7 = *(const f16x8r*)(hrow + 7 * 32);
       hl7 = *(const f16x8r*)(hrow + 7 * 32 + 16);
+      w15[0] = wl[32 * 64];
+      w15[1] = wl[33 * 64];
       __builtin_amdgcn_sched_barrier(0);
       mfma7(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -4041,5 +4050,11 @@ void upload_norm_lut(const float* lut256, hipStream_t s) {
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(c_norm_lut), lut256, 256 * sizeof(float), 0,
                                hipMemcpyHostToDevice, s);
 }
+
+
+// One empty launch from this translation unit: the runtime loads a code object (and sets a stream's queue up) at the
+// first launch that needs it; crnn_api.hip does these at device set-up so that no later call is the first one.
+__global__ void warm_main_kernel() {}
+void launch_warm_main(hipStream_t s) { hipLaunchKernelGGL(warm_main_kernel, dim3(1), dim3(64), 0, s); }
 
 }  // namespace crnn

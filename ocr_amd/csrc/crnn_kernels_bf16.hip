@@ -751,4 +751,10 @@ void pack_whh_bf16(const float* whh_fwd, const float* whh_rev, uint16_t* packed)
   }
 }
 
+
+// One empty launch from this translation unit: the runtime loads a code object (and sets a stream's queue up) at the
+// first launch that needs it; crnn_api.hip does these at device set-up so that no later call is the first one.
+__global__ void warm_bf16_kernel() {}
+void launch_warm_bf16(hipStream_t s) { hipLaunchKernelGGL(warm_bf16_kernel, dim3(1), dim3(64), 0, s); }
+
 }  // namespace crnn

@@ -396,4 +396,10 @@ void launch_cls_select(const uint16_t* L, const float* A, const float* W, const 
   if (f16) hipLaunchKernelGGL(cls_select_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, L, A, W, bias, anorm, wnorm, idx, M, N, K, ldl, wnmax);
   else hipLaunchKernelGGL(cls_select_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, L, A, W, bias, anorm, wnorm, idx, M, N, K, ldl, wnmax);
 }
+
+// One empty launch from this translation unit: the runtime loads a code object (and sets a stream's queue up) at the
+// first launch that needs it; crnn_api.hip does these at device set-up so that no later call is the first one.
+__global__ void warm_nopk_kernel() {}
+void launch_warm_nopk(hipStream_t s) { hipLaunchKernelGGL(warm_nopk_kernel, dim3(1), dim3(64), 0, s); }
+
 }  // namespace crnn

@@ -42,6 +42,7 @@ def main():
         print("check_isa: llvm-objdump not found (set LLVM_BIN to the ROCm LLVM bin directory); the library was NOT checked")
         return 2
     bad = []
+    scratch = []
     n_pk = 0
     with tempfile.TemporaryDirectory() as td:
         tmp = os.path.join(td, os.path.basename(lib))
@@ -65,6 +66,22 @@ def main():
                     s = SEL.search(line)
                     if s and "1" in s.group(1):
                         bad.append((fn, line.strip().split("//")[0].strip()))
+            # private (scratch) memory: the runtime allocates it on a queue at a kernel's first launch there, which is what
+            # crnn_forward_device_noalloc promises not to cause -- no kernel of the library may need any
+            notes = subprocess.run([LLVM + "/llvm-readobj", "--notes", os.path.join(td, co)], capture_output=True, text=True).stdout
+            name = "?"
+            for line in notes.splitlines():
+                m = re.match(r"\s*\.name:\s+(\S+)", line)
+                if m:
+                    name = m.group(1)
+                m = re.match(r"\s*\.private_segment_fixed_size:\s+(\d+)", line)
+                if m and int(m.group(1)) > 0:
+                    scratch.append((name, int(m.group(1))))
+    if scratch:
+        print("check_isa: %d kernels use scratch memory (register spills or stack arrays):" % len(scratch))
+        for k, n in scratch:
+            print("  %s   %d bytes per lane" % (k, n))
+        return 1
     if bad:
         kernels = sorted(set(b[0] for b in bad))
         print("check_isa: %d packed-fp32 instructions with op_sel in %d kernels (move them to crnn_kernels_nopk.hip):" % (len(bad), len(kernels)))
@@ -72,7 +89,7 @@ def main():
             ex = next(b[1] for b in bad if b[0] == k)
             print("  %s   e.g. %s" % (k, ex))
         return 1
-    print("check_isa: ok (%d packed-fp32 instructions, none with op_sel)" % n_pk)
+    print("check_isa: ok (%d packed-fp32 instructions, none with op_sel; no kernel uses scratch memory)" % n_pk)
     return 0
 
 
