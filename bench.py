@@ -461,12 +461,13 @@ def main():
     # GEMMs, not the direct form), algorithmic bytes].  An f16x3 kernel executes THREE fp16 MFMA products per fp32
     # product: its roofline is the fp16 MFMA's, with 3x those FLOPs.
     wino4_names = [n for n in order if n.endswith("_f4")]
+    wino4pp_names = [n for n in order if n.endswith("_f4pp")]     # the same GEMMs in the ping-pong form (round 3)
     fused4_names = [n for n in order if n.endswith("_fused4")]      # GEMMs + output transform in one kernel (f16x3 only)
     lin_on = fp32 and os.environ.get("CRNN_LIN_GEMM", "1") != "0"
     lin_names = [n for n in order if lin_on and n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
     other_names = [n for n in order if (n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier") or
                                         (n.startswith("conv") and not n.startswith("conv0_pool0") and "_win" not in n and "_wout" not in n))
-                   and n not in wino4_names + fused4_names + lin_names]
+                   and n not in wino4_names + wino4pp_names + fused4_names + lin_names]
 
     def family(kernel, names, what, products, peak):
         ms = sum(acc[n][0] for n in names)
@@ -486,11 +487,17 @@ def main():
             f["direct_form_over_f32_mfma_peak"] = round(direct / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
         return f
     fams = []
+    if wino4pp_names:
+        fams.append(family("wino4_gemm_h3_pp_kernel", wino4pp_names,
+                           "the 36 Winograd F(4x4,3x3) component GEMMs of a layer (conv4, conv5: N = 512, K <= 512) as one persistent "
+                           "launch of 256 x 128 units on the fp16 MFMA: operands as (hi, lo) fp16 pairs, 3 MFMA products per fp32 "
+                           "product, 64 x 64 wave tiles, two groups of four MFMA waves one slot apart (ping-pong), four loader waves",
+                           3, PEAK_BF16_MFMA_TFLOPS))
     if wino4_names:
         if h3:
             fams.append(family("wino4_gemm_h3_lw_kernel", wino4_names,
-                               "Winograd component GEMMs of a layer -- 36 for F(4x4,3x3) on the layers that keep a product tensor "
-                               "(conv3-5 by default), 5 for conv6's 1-D F(4,2) -- as one persistent launch of 128x128 units on the fp16 "
+                               "Winograd component GEMMs of a layer -- 36 for F(4x4,3x3) (conv3; the others when the ping-pong form is "
+                               "off), 5 for conv6's 1-D F(4,2) -- as one persistent launch of 128x128 units on the fp16 "
                                "MFMA, operands as (hi, lo) fp16 pairs, 3 MFMA products per fp32 product, loader waves, product stores "
                                "through LDS (wino4_gemm_h3_kernel below K = 256)", 3, PEAK_BF16_MFMA_TFLOPS))
         else:
@@ -522,7 +529,7 @@ def main():
     # runs, gfx950 x2 read correction; tools/pmc_traffic.py).  PMC counters cannot be collected from inside this process,
     # so the figure comes from profiles/ and the line says which file and which commit of it.
     traffic, traffic_src = None, None
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         tp = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, args.precision))
         if not os.path.exists(tp):
             continue
@@ -550,7 +557,7 @@ def main():
         if n == "cls_filter_bf16":
             mfma_s += cls_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12)
         elif acc[n][1] and not n.startswith("conv0_pool0"):
-            is_h3 = h3 and (n in wino4_names or n in fused4_names or n in ("lstm0_ih", "lstm1_ih", "emb0"))
+            is_h3 = h3 and (n in wino4_names or n in wino4pp_names or n in fused4_names or n in ("lstm0_ih", "lstm1_ih", "emb0"))
             mfma_s += (3.0 * acc[n][1] / (PEAK_BF16_MFMA_TFLOPS * 1e12)) if is_h3 else acc[n][1] / ((PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS) * 1e12)
     serial_ms = sum(acc[n][0] for n in order)
     peak = dom["peak"]

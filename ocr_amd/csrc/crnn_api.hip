@@ -598,7 +598,8 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     w.V = wino_v; w.U = h3 ? (const float*)h->d_wino4h[layer] : h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp;
     w.N = Co; w.Cin = Cin; w.ncomp = 36; w.h3 = h3;
     launch_wino4_gemm(w, s);
-    kmark(h, wn4[1][layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * 36 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
+    static const char* wn4pp[7] = {"", "conv1_f4pp", "conv2_f4pp", "conv3_f4pp", "conv4_f4pp", "conv5_f4pp", ""};
+    kmark(h, wino4_gemm_uses_pp(w) ? wn4pp[layer] : wn4[1][layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * 36 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
     float* dst = pool_out ? pool_out : (pool21_out ? pool21_out : (float*)C);
     launch_wino4_out(wino_m, h->d_conv_b[layer], dst, wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1,
                      pool_out ? 1 : (pool21_out ? 2 : 0), s, h3 ? vs : nullptr, h->wino4_us[layer]);
@@ -621,7 +622,7 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     w.V = wino_v; w.U = h3 ? (const float*)h->d_wino4h[6] : h->d_wino4[6]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co;
     w.Cin = 2 * Cin; w.ncomp = 5; w.h3 = h3;
     launch_wino4_gemm(w, s);
-    kmark(h, "conv6_f4", 2.0 * 5 * tiles * Co * 2 * Cin, 4.0 * 5 * ((double)tiles * 2 * Cin + (double)Co * 2 * Cin + (double)tiles * Co));
+    kmark(h, wino4_gemm_uses_pp(w) ? "conv6_f4pp" : "conv6_f4", 2.0 * 5 * tiles * Co * 2 * Cin, 4.0 * 5 * ((double)tiles * 2 * Cin + (double)Co * 2 * Cin + (double)tiles * Co));
     launch_wino42_out(wino_m, h->d_conv_b[6], (float*)C, n, Wout, Co, h->cfg.leaky_relu ? 2 : 1, s, h3 ? vs : nullptr,
                       h->wino4_us[6]);
     kmark(h, "conv6_wout4", 0, 4.0 * (5.0 * tiles * Co + (double)n * Wout * Co));

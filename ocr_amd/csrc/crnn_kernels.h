@@ -206,6 +206,7 @@ struct Wino4Gemm {
   int ncomp;        // number of component GEMMs: 36 (F(4x4,3x3)); 5 for conv6's 1-D F(4,2)
   int h3;           // operands in the f16x3 format (crnn_kernels.hip): V and U hold (hi, lo) fp16 pairs, M leaves scaled
 };
+bool wino4_gemm_uses_pp(const Wino4Gemm& p);   // this launch runs wino4_gemm_h3_pp_kernel (else the loader-wave / plain form)
 // conv0 + activation + pool0 + conv1's F(4x4) input transform (f16x3 V, per-tile scales) in one kernel; in: [B,32,W] fp32
 void launch_conv0_win4(const float* in, const float* w9x64, const float* bias, float* V, float* vs,
                        const int32_t* w1valid, int B, int W, int act, hipStream_t s);

@@ -2611,6 +2611,19 @@ void launch_lin_gemm(const ConvGemm& p0, hipStream_t s) {
 }
 
 
+// Which launches take the ping-pong form: 256-tile units (wino4_pad rounds to 256 from 1024 tiles up).  Measured alone on
+// the device at 256 lines against the loader-wave form: conv4 0.162 against 0.181 ms, conv5 0.250 against 0.277, but conv3
+// (N = 256: a unit is only 8 K steps before its 64 store instructions per wave) 0.193 against 0.169 and conv6 (K = 1024, 5
+// components) 0.090 against 0.083 -- so it takes the layers with N >= 512 and K <= 512.  In the pipeline the two forms are
+// within 0.5 % of each other (the chip is power-bound there).  CRNN_GEMM_PP=0: never; 2: every layer it can take.
+// (Read per launch: bench.py switches it between handles for its A/B line.)
+bool wino4_gemm_uses_pp(const Wino4Gemm& p) {
+  const char* ppe = getenv("CRNN_GEMM_PP");
+  const int ppm = ppe ? atoi(ppe) : 1;
+  return p.h3 && ppm != 0 && p.Cin >= 256 && p.ntile_pad >= 1024 && p.ntile_pad % 256 == 0 && p.N % 128 == 0 &&
+         (ppm == 2 || (p.N >= 512 && p.Cin <= 512));
+}
+
 void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
   static const int shape = getenv("CRNN_WINO4_SHAPE") ? atoi(getenv("CRNN_WINO4_SHAPE")) : 4;
   const int nwn = (shape == 2 || p.N % 128) ? 2 : 4;
@@ -2621,15 +2634,7 @@ void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
   if (p.h3) {   // operands in the f16x3 format (N % 128 == 0 checked by the caller)
     const int u3 = p.ncomp * (p.ntile_pad / 128) * (p.N / 128);
     static const int h3lw = getenv("CRNN_H3_LW") ? atoi(getenv("CRNN_H3_LW")) : 256;   // loader waves from this K (0 = never)
-    const char* ppe = getenv("CRNN_GEMM_PP");      // read per launch: bench.py switches it between handles for its A/B line
-    const bool pp = !(ppe && atoi(ppe) == 0);
-    // the ping-pong form: 256-tile units (wino4_pad rounds to 256 from 1024 tiles up).  Measured alone on the device at 256
-    // lines against the loader-wave form: conv4 0.162 against 0.181 ms, conv5 0.250 against 0.277, but conv3 (N = 256: a unit
-    // is only 8 K steps before its 64 store instructions per wave) 0.193 against 0.169 and conv6 (K = 1024, 5 components)
-    // 0.090 against 0.083 -- so it takes the layers with N >= 512 and K <= 512.  In the four-lane pipeline the two forms
-    // are within 0.5 % of each other (the chip is power-bound there).  CRNN_GEMM_PP=2: every layer it can take.
-    const int ppm = ppe ? atoi(ppe) : 1;
-    if (pp && p.Cin >= 256 && p.ntile_pad >= 1024 && p.ntile_pad % 256 == 0 && (ppm == 2 || (p.N >= 512 && p.Cin <= 512))) {
+    if (wino4_gemm_uses_pp(p)) {
       const int u2 = p.ncomp * (p.ntile_pad / 256) * (p.N / 128);
       hipLaunchKernelGGL(wino4_gemm_h3_pp_kernel, dim3(u2 < persistent_blocks() ? 8 * ((u2 + 7) / 8) : persistent_blocks()), dim3(768), 0, s, p);
     } else if (h3lw > 0 && p.Cin >= h3lw)

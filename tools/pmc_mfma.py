@@ -15,7 +15,7 @@ per_cycle = 16.0 if kind == "f32" else 256.0
 f = (glob.glob(d + '/*counter_collection.csv') + glob.glob(d + '/*/*counter_collection.csv'))[0]
 acc = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
-    if 'crnn::' not in r['Kernel_Name']:
+    if 'crnn::' not in r['Kernel_Name'] or 'crnn::warm_' in r['Kernel_Name']:
         continue
     key = (r['Kernel_Name'].split('(')[0].replace('crnn::', ''), int(r['Grid_Size']))
     acc.setdefault(key, collections.defaultdict(list))[r['Counter_Name']].append(float(r['Counter_Value']))

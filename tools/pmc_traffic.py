@@ -38,16 +38,21 @@ if MODE.endswith(".json"):     # the launch order of a step as a bench.py line o
 
 def per_launch(d, counter):
     f = (glob.glob(d + '/*counter_collection.csv') + glob.glob(d + '/*/*counter_collection.csv'))[0]
-    rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and 'crnn::' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and 'crnn::' in r['Kernel_Name']
+            and 'crnn::warm_' not in r['Kernel_Name']]      # (set-up launches, not part of a step)
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     vals = [float(r['Counter_Value']) for r in rows]
     names = [r['Kernel_Name'].split('(')[0].replace('crnn::', '') for r in rows]
     n = len(ORDER)
-    steps = len(vals) // n
+    # a step starts at its normalize launch; only steps with exactly the launches of ORDER count (the asynchronous form
+    # of a step queues one more launch behind each hidden-split recurrence, the gated repeat: those steps are left out)
+    starts = [i for i, nm in enumerate(names) if nm.startswith('normalize_kernel')] + [len(names)]
+    steps = [(a, b) for a, b in zip(starts[:-1], starts[1:]) if b - a == n]
+    assert len(steps) >= 2, "no two steps of %d launches in %s" % (n, f)
     out = collections.OrderedDict()
     for i, nm in enumerate(ORDER):
-        xs = [vals[s * n + i] for s in range(1, steps)]       # skip the first (cold) step
-        out[nm] = (sum(xs) / len(xs), names[i])
+        xs = [vals[a + i] for a, _ in steps[1:]]       # skip the first (cold) step
+        out[nm] = (sum(xs) / len(xs), names[steps[1][0] + i])
     return out
 
 
