@@ -94,11 +94,9 @@ struct crnn_handle {
   std::vector<float> h_conv_w[7], h_conv_b[7];
   std::vector<float> h_wih[2], h_bih[2], h_whhp[2], h_emb_w[2], h_emb_b[2], h_lin_w, h_lin_b;
   float lut[256];
-  // Winograd F(2x2,3x3) weights U[16][Cout][Cin] for the layers in wino_mask (fp32 path only)
-  std::vector<float> h_wino[7];
-  unsigned wino_mask = 0;
-  // Winograd F(4x4,3x3) weights U[36][Cout][Cin] for the layers in wino4_mask (they take precedence over
-  // wino_mask for batches of at least wino4_min_n lines; measured faster from one line up, so the default is 1)
+  // Winograd F(4x4,3x3) weights U[36][Cout][Cin] for the layers in wino4_mask (fp32 path; used for batches of at least
+  // wino4_min_n lines: measured faster from one line up, so the default is 1; a layer outside the mask runs as direct
+  // implicit GEMM)
   std::vector<float> h_wino4[7];
   unsigned wino4_mask = 0;
   // f16x3 (CRNN_F16X3, default on; fp32 precision only): the Winograd GEMMs of the F(4x4) / F(4,2) layers run on the fp16
@@ -134,7 +132,6 @@ struct crnn_handle {
   // (at most one hidden-split kernel runs on a DEVICE at a time, whichever handle of this process launched it:
   // g_split below)
   std::atomic<int64_t> split_timeouts{0};   // batches repeated because the hidden-split recurrence gave up (crnn_split_timeouts)
-  bool wino_fused = true;   // GEMM + output transform in one kernel (CRNN_WINO_FUSED=0: separate kernels)
   // Load-time channel equalisation (equalize_channels below; CRNN_EQUALIZE=0: off): the power-of-two factor that
   // output channel c of conv i (chan_scale[i]) / of the first embedding (chan_scale[7]) carries relative to the
   // reference's activation.  crnn_debug_stage divides it out again; nothing else sees it.
@@ -156,7 +153,6 @@ struct crnn_handle {
   float* d_emb_b[2] = {};
   float* d_lin_w = nullptr;
   float* d_lin_b = nullptr;
-  float* d_wino[7] = {};
   float* d_wino4[7] = {};
   float* d_cls_wnorm = nullptr;
   float* d_zero_bias = nullptr;   // 512 zeros: the Winograd GEMMs add the bias in the output transform
@@ -324,8 +320,6 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     for (int i = 0; i < 7; i++)
       if ((rc = upload16(h, h->hb_conv_w[i], &h->db_conv_w[i]))) return rc;
     for (int i = 0; i < 7; i++)
-      if ((rc = upload(h, h->h_wino[i], &h->d_wino[i]))) return rc;
-    for (int i = 0; i < 7; i++)
       if ((rc = upload(h, h->h_wino4[i], &h->d_wino4[i]))) return rc;
     for (int i = 0; i < 7; i++)
       if ((rc = upload16(h, h->h_wino4h[i], &h->d_wino4h[i]))) return rc;
@@ -456,17 +450,7 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
   p.pmax = take(n * g.T * ntn);
   p.pidx = (int32_t*)take(n * g.T * ntn);
   {
-    // tiles and channels of conv1..5: (n*8*ceil(W1/2), 64->128), (n*4*ceil(W2/2), 128->256), (.., 256->256),
-    // (n*2*ceil(W3/2), 256->512), (.., 512->512)
-    const size_t tl[6] = {0, n * 8 * (size_t)((g.W1 + 1) / 2), n * 4 * (size_t)((g.W2 + 1) / 2),
-                          n * 4 * (size_t)((g.W2 + 1) / 2), n * 2 * (size_t)((g.W3 + 1) / 2),
-                          n * 2 * (size_t)((g.W3 + 1) / 2)};
     size_t vmax = 0, mmax = 0;
-    for (int i = 1; i <= 5; i++)
-      if ((h->wino_mask >> i) & 1u) {
-        vmax = std::max(vmax, 16 * tl[i] * NM[i - 1]);
-        if (!h->wino_fused) mmax = std::max(mmax, 16 * tl[i] * NM[i]);
-      }
     if (h->wino6 && use_wino4(h, (int)n)) {
       const size_t tp = (size_t)wino4_pad((long)n * ((g.T + 3) / 4));
       vmax = std::max(vmax, 5 * tp * 1024);
@@ -628,39 +612,6 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     kmark(h, "conv6_wout4", 0, 4.0 * (5.0 * tiles * Co + (double)n * Wout * Co));
     return false;
   }
-  if (!b16 && ((h->wino_mask >> layer) & 1u) && wino_v) {
-    // Winograd F(2x2,3x3): input transform, 16 batched GEMMs (K = Cin), output transform
-    static const char* wn[3][7] = {{"", "conv1_win", "conv2_win", "conv3_win", "conv4_win", "conv5_win", ""},
-                                   {"", "conv1", "conv2", "conv3", "conv4", "conv5", ""},
-                                   {"", "conv1_wout", "conv2_wout", "conv3_wout", "conv4_wout", "conv5_wout", ""}};
-    const int Co = NM[layer];
-    const long tiles = (long)n * (Hin / 2) * ((Win + 1) / 2);
-    hipStream_t s = tl_cur->stream;
-    launch_wino_in((const float*)A, wino_v, n, Hin, Win, Cin, s);
-    kmark(h, wn[0][layer], 0, 4.0 * ((double)n * Hin * Win * Cin + 16.0 * tiles * Cin));
-    if (h->wino_fused) {
-      WinoGemm w{};
-      w.V = wino_v; w.U = h->d_wino[layer]; w.bias = h->d_conv_b[layer]; w.y = (float*)C; w.wvalid = wvalid;
-      w.ntile = (int)tiles; w.N = Co; w.Cin = Cin; w.B = n; w.H = Hin; w.W = Win;
-      w.act = h->cfg.leaky_relu ? 2 : 1; w.pool = pool_out ? 1 : 0;
-      if (pool_out) w.y = pool_out;
-      launch_wino_gemm(w, s);
-      kmark(h, pool_out ? "conv1_pool1" : wn[1][layer], 2.0 * 16 * tiles * Co * Cin,
-            4.0 * (16.0 * tiles * Cin + 16.0 * Co * Cin +
-                   (pool_out ? (double)n * (Hin / 2) * (Win / 2) : (double)n * Hin * Win) * Co));
-      return pool_out != nullptr;
-    }
-    ConvGemm q{};
-    q.A = wino_v; q.Wt = h->d_wino[layer]; q.bias = h->d_zero_bias; q.C = wino_m; q.wvalid = nullptr;
-    q.M = (int)tiles; q.N = Co; q.K = Cin; q.ldc = Co;
-    q.Hin = q.Win = q.Hout = q.Wout = 1; q.Cin = Cin; q.ks = 1; q.pad = 0; q.act = 0;
-    q.nbatch = 16; q.bsA = tiles * Cin; q.bsW = (long)Co * Cin; q.bsC = tiles * Co;
-    launch_conv_gemm(q, s);
-    kmark(h, wn[1][layer], 2.0 * 16 * tiles * Co * Cin, 4.0 * 16 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
-    launch_wino_out(wino_m, h->d_conv_b[layer], (float*)C, wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1, s);
-    kmark(h, wn[2][layer], 0, 4.0 * (16.0 * tiles * Co + (double)n * Hin * Win * Co));
-    return false;
-  }
   ConvGemm p{};
   p.A = (const float*)A; p.Wt = b16 ? (const float*)h->db_conv_w[layer] : h->d_conv_w[layer];
   p.bias = h->d_conv_b[layer]; p.C = (float*)C; p.wvalid = wvalid;
@@ -745,7 +696,9 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   static const bool pipe_split = !(getenv("CRNN_PIPE_SPLIT") && atoi(getenv("CRNN_PIPE_SPLIT")) == 0);
   // (may_alloc == false: crnn_forward_device_noalloc -- the split form needs its sync buffer and the chain's event)
   const bool gated = !allow_split && may_alloc && pipe_split && h->d_whh3[0] != nullptr;
-  const bool split = (allow_split || gated) && !b16 && h->cfg.lstm && n <= h->split_max && (double)M * 2048.0 < 2.0e9;
+  // (the split form exists for the f16x3 recurrence only: CRNN_F16X3=0 / CRNN_REC_H3=0 keep the one-workgroup f32 kernel)
+  const bool split = (allow_split || gated) && !b16 && h->cfg.lstm && h->d_whh3[0] != nullptr && n <= h->split_max &&
+                     (double)M * 2048.0 < 2.0e9;
   unsigned* d_sync = nullptr;
   if (split) {
     const bool fresh = tl_cur->sync.p == nullptr;
@@ -763,9 +716,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       if (ch.pid != getpid()) { ch.ev = nullptr; ch.pid = getpid(); }     // a forked child starts its own chain
       if (!ch.ev) (void)hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming);
       if (ch.ev) (void)hipStreamWaitEvent(s, ch.ev, 0);
-      static const bool sh3 = !(getenv("CRNN_SPLIT_H3") && atoi(getenv("CRNN_SPLIT_H3")) == 0);
-      if (sh3 && h->d_whh3[l]) launch_lstm_rec_split_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], d_sync, s);
-      else launch_lstm_rec_split(p.xp, h->d_whhp[l], out, tlen, n, g.T, d_sync, s);
+      launch_lstm_rec_split_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], d_sync, s);
       if (ch.ev) (void)hipEventRecord(ch.ev, s);
       if (gated) launch_lstm_rec_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], s, d_sync);
     }
@@ -1064,12 +1015,8 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
     const int q = e ? atoi(e) : 4;
     if (q < 8 && h->nlanes > 3 && !getenv("CRNN_KEEP_LANES")) h->nlanes = 3;
   }
-  // Winograd layers (bit i = conv i, i in 1..5): default conv3..5 (measured best); CRNN_WINOGRAD=<mask> overrides (0 = off)
-  h->wino_mask = cfg->precision == CRNN_FP32 ? 0x3Eu : 0u;
-  if (const char* e = getenv("CRNN_WINO_FUSED")) h->wino_fused = atoi(e) != 0;
-  // F(4x4) layers (bit i = conv i): default conv1..5.  conv1 (K = 64 per component, a product tensor twice the size
-  // of V) is only equal to the fused F(2x2) kernel alone on the device but 2 % faster in the pipeline; with the
-  // textbook points 0, +-1, +-2 its error was too large (its input has the widest dynamic range), with the points
+  // F(4x4) layers (bit i = conv i): default conv1..5; a layer outside the mask runs as direct implicit GEMM.  With the
+  // textbook points 0, +-1, +-2 conv1's error was too large (its input has the widest dynamic range), with the points
   // the kernels use now it is not.  CRNN_WINOGRAD_F4=<mask> overrides (0 = off), CRNN_WINO4_MIN_N=<lines>
   h->wino4_mask = cfg->precision == CRNN_FP32 ? 0x3Eu : 0u;
   if (const char* e = getenv("CRNN_WINOGRAD_F4")) h->wino4_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
@@ -1084,9 +1031,6 @@ int crnn_create(const crnn_config* cfg, crnn_handle** out) {
   if (cfg->precision != CRNN_FP32) h->cls_filter = false;
   if (cfg->precision != CRNN_FP32) h->wino6 = false;
   if (const char* e = getenv("CRNN_LSTM_SPLIT")) h->split_max = atoi(e);
-  if (const char* e = getenv("CRNN_WINOGRAD")) h->wino_mask = cfg->precision == CRNN_FP32 ? ((unsigned)strtoul(e, nullptr, 0) & 0x3Eu) : 0u;
-  // a layer that always runs as F(4x4) needs no F(2x2) weight set (neither built at load nor uploaded)
-  if (h->wino4_min_n <= 1) h->wino_mask &= ~h->wino4_mask;
   for (int v = 0; v < 256; v++) h->lut[v] = (float)(((double)v / 255.0 - 0.5) / 0.5);
   *out = h;
   return 0;
@@ -1203,27 +1147,6 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
               }
             }
           }
-    }
-  }
-  // Winograd weights: U = G g G^T per (co, ci), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], BN folded first
-  for (int i = 1; i <= 5; i++) {
-    if (!((h->wino_mask >> i) & 1u)) continue;
-    const int cin = NM[i - 1], co = NM[i];
-    const std::vector<double>& w = fw[i];
-    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    h->h_wino[i].assign((size_t)16 * co * cin, 0.f);
-    for (int o = 0; o < co; o++) {
-      for (int c = 0; c < cin; c++) {
-        double gg[3][3], t[4][3];
-        for (int a = 0; a < 3; a++)
-          for (int b = 0; b < 3; b++) gg[a][b] = w[(((size_t)o * cin + c) * 3 + a) * 3 + b];
-        for (int a = 0; a < 4; a++)
-          for (int b = 0; b < 3; b++) t[a][b] = G[a][0] * gg[0][b] + G[a][1] * gg[1][b] + G[a][2] * gg[2][b];
-        for (int a = 0; a < 4; a++)
-          for (int b = 0; b < 4; b++)
-            h->h_wino[i][((size_t)(a * 4 + b) * co + o) * cin + c] =
-                (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
-      }
     }
   }
   // F(4x4,3x3) weights (points 0, 1, -1, 2, -1/2, inf): U = G g G^T,
@@ -1796,7 +1719,6 @@ void crnn_destroy(crnn_handle* h) {
       (void)hipFree(h->d_emb_w[l]); (void)hipFree(h->d_emb_b[l]);
     }
     (void)hipFree(h->d_lin_w); (void)hipFree(h->d_lin_b); (void)hipFree(h->db_lin_w); (void)hipFree(h->d_zero_bias);
-    for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4[i]);
     for (int i = 0; i < 7; i++) (void)hipFree(h->d_wino4h[i]);
     for (int l = 0; l < 2; l++) (void)hipFree(h->d_wih_h3[l]);

@@ -167,36 +167,10 @@ __device__ __forceinline__ void store_epilogue(const crnn_f32x16 (&acc)[2][2], c
 }
 #endif
 
-// Winograd F(2x2,3x3) for the 3x3 / pad 1 convolutions (fp32): 2.25x fewer MFMA FLOPs than the direct
-// form.  x NHWC [B,H,W,C] (H even) -> V[16][B*(H/2)*ceil(W/2)][C] (input transform B^T d B);
-// 16 batched GEMMs with U[16][Cout][C] (= G g G^T, BatchNorm folded, made at load time) give
-// Mo[16][tiles][Cout]; the output transform A^T m A adds bias, applies the activation and the
-// per-line width mask and writes NHWC [B,H,W,Cout].
-void launch_wino_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s);
-void launch_wino_out(const float* Mo, const float* bias, float* y, const int32_t* wvalid, int B, int H,
-                     int W, int Cout, int act, hipStream_t s);
-
-// Fused form of the two steps above: one block owns 128 tiles x 64 output channels, runs the 16
-// component GEMMs back to back (an effective K of 16*Cin, so short-K layers keep the MFMA pipe
-// full), folds each product into the four 2x2 outputs in registers (A^T m A has only 0/+-1
-// coefficients) and writes bias + activation + mask straight to NHWC -- Mo never exists.
-// pool = 1 additionally takes the max over the 2x2 tile (MaxPool 2x2/2 == one Winograd tile) and
-// writes [B,H/2,W/2,N] (W even).  Requires N % 64 == 0, Cin % 32 == 0, H even.
-struct WinoGemm {
-  const float* V;         // [16][ntile][Cin]
-  const float* U;         // [16][N][Cin]
-  const float* bias;      // [N]
-  float* y;               // NHWC [B,H,W,N]  (pool: [B,H/2,W/2,N])
-  const int32_t* wvalid;  // per-line valid output width (pre-pool columns) or nullptr
-  int ntile, N, Cin, B, H, W, act, pool;
-  int m_off, m_cnt;       // tiles [m_off, m_off + m_cnt) are this launch's share (set by launch_wino_gemm)
-};
-void launch_wino_gemm(const WinoGemm& p, hipStream_t s);
-
 // Winograd F(4x4,3x3) (fp32): 36 components per 4x4 output tile, 2.25 multiplies per output and input
 // channel instead of 9 (direct) or 4 (F(2x2)).  Three kernels: input transform x -> V[36][ntile_pad][Cin],
 // 36 GEMMs V U^T -> M[36][ntile_pad][Cout] in one persistent launch, output transform (+ bias, activation,
-// width mask, optionally MaxPool 2x2/2) M -> NHWC.  H % 4 == 0; ntile_pad = tiles rounded up to 128
+// width mask, optionally MaxPool 2x2/2) M -> NHWC.  H % 4 == 0; ntile_pad = wino4_pad(tiles)
 // (the padding rows of V are never written and their products never read).
 struct Wino4Gemm {
   const float* V;   // [36][ntile_pad][Cin]
@@ -260,8 +234,6 @@ void launch_lstm_rec(const float* xp, const float* whh_packed, float* rec, const
 // registers, h exchanged every step through rec itself (write-through stores; the rows double as arrival flags).
 // tmo: one device word the caller has zeroed, set to 1 if a hand-off timed out (the caller then repeats the
 // recurrence with launch_lstm_rec).
-void launch_lstm_rec_split(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,
-                           int T, unsigned* tmo, hipStream_t s);
 // the same on the fp16 MFMA in the f16x3 form (weights from pack_whh_h3, unscale as for launch_lstm_rec_h3): bit-identical to
 // lstm_rec_h3_kernel
 void launch_lstm_rec_split_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T,
@@ -282,8 +254,6 @@ void launch_argmax_partials(const float* pmax, const int32_t* pidx, int32_t* idx
                             hipStream_t s);
 
 // row-wise argmax over nclass (ties -> lowest index); logits [M][ld] -> idx [M]
-void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld, hipStream_t s);
-
 // greedy CTC collapse (util.py:16-22): idx [B][T] -> out [B][T] alphabet positions (class-1), len [B]
 void launch_ctc(const int32_t* idx, const int32_t* tlen, int32_t* out, int32_t* len, int B, int T,
                 hipStream_t s);

@@ -169,587 +169,21 @@ void launch_conv_gemm(const ConvGemm& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
-// Winograd F(2x2,3x3) transforms (fp32, HBM-bound elementwise kernels; float4 over channels).
-// B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  A^T = [1 1 1 0; 0 1 -1 -1].
-// ---------------------------------------------------------------------------
-// One thread owns a COLUMN of tiles (all tile rows of one line at one tile x, 4 channels): walking down,
-// each 4x4 input patch shares its top two rows with the previous tile's bottom two, so every input row
-// is loaded once per thread; horizontally adjacent threads read overlapping columns at the same time
-// (L1/L2 hits).  HBM reads drop from 2x the input (one thread per tile) to ~1x.
-__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V,
-                                                      int B, int H, int W, int C) {
-  const int th = H >> 1, tw = (W + 1) >> 1, C4 = C >> 2;
-  const long ntile = (long)B * th * tw;
-  const long total = (long)B * tw * C4;
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const long r = i / C4;
-    const int tx = (int)(r % tw);
-    const int b = (int)(r / tw);
-    bool okx[4];
-    const float* px[4];
-#pragma unroll
-    for (int dx = 0; dx < 4; dx++) {
-      const int xx = 2 * tx - 1 + dx;
-      okx[dx] = (unsigned)xx < (unsigned)W;
-      px[dx] = x + ((long)b * H * W + (okx[dx] ? xx : 0)) * C + c4 * 4;
-    }
-    auto row = [&](int yy, f32x4 (&d)[4]) {
-      const bool oky = (unsigned)yy < (unsigned)H;
-#pragma unroll
-      for (int dx = 0; dx < 4; dx++) d[dx] = (oky && okx[dx]) ? *(const f32x4*)(px[dx] + (long)yy * W * C) : z;
-    };
-    f32x4 d[4][4];
-    row(-1, d[0]);
-    row(0, d[1]);
-    for (int ty = 0; ty < th; ty++) {
-      row(2 * ty + 1, d[2]);
-      row(2 * ty + 2, d[3]);
-      const long t = ((long)b * th + ty) * tw + tx;
-      f32x4 u[4][4];   // B^T d (rows)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        u[0][j] = d[0][j] - d[2][j];
-        u[1][j] = d[1][j] + d[2][j];
-        u[2][j] = d[2][j] - d[1][j];
-        u[3][j] = d[1][j] - d[3][j];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) {   // (B^T d) B (columns)
-        const f32x4 v0 = u[k][0] - u[k][2];
-        const f32x4 v1 = u[k][1] + u[k][2];
-        const f32x4 v2 = u[k][2] - u[k][1];
-        const f32x4 v3 = u[k][1] - u[k][3];
-        float* o = V + ((long)(k * 4) * ntile + t) * C + c4 * 4;
-        *(f32x4*)(o) = v0;
-        *(f32x4*)(o + ntile * C) = v1;
-        *(f32x4*)(o + 2 * ntile * C) = v2;
-        *(f32x4*)(o + 3 * ntile * C) = v3;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) { d[0][j] = d[2][j]; d[1][j] = d[3][j]; }
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
-                                                       float* __restrict__ y, const int32_t* __restrict__ wvalid,
-                                                       int B, int H, int W, int Co, int act) {
-  const int th = H >> 1, tw = (W + 1) >> 1, C4 = Co >> 2;
-  const long ntile = (long)B * th * tw;
-  const long total = ntile * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const long t = i / C4;
-    const int tx = (int)(t % tw);
-    const long r = t / tw;
-    const int ty = (int)(r % th);
-    const int b = (int)(r / th);
-    f32x4 m[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) m[k][j] = *(const f32x4*)(Mo + ((long)(k * 4 + j) * ntile + t) * Co + c4 * 4);
-    f32x4 s0[4], s1[4];   // A^T m
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      s0[j] = m[0][j] + m[1][j] + m[2][j];
-      s1[j] = m[1][j] - m[2][j] - m[3][j];
-    }
-    const f32x4 bs = *(const f32x4*)(bias + c4 * 4);
-    f32x4 o[2][2];
-    o[0][0] = s0[0] + s0[1] + s0[2] + bs;
-    o[0][1] = s0[1] - s0[2] - s0[3] + bs;
-    o[1][0] = s1[0] + s1[1] + s1[2] + bs;
-    o[1][1] = s1[1] - s1[2] - s1[3] + bs;
-    const int wv = wvalid ? wvalid[b] : W;
-#pragma unroll
-    for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-      for (int dx = 0; dx < 2; dx++) {
-        const int xx = 2 * tx + dx;
-        if (xx >= W) continue;
-        f32x4 v = o[dy][dx];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          float e = v[c];
-          if (act == 1) e = e > 0.f ? e : 0.f;
-          else if (act == 2) e = e > 0.f ? e : 0.2f * e;
-          if (xx >= wv) e = 0.f;
-          v[c] = e;
-        }
-        *(f32x4*)(y + (((long)b * H + 2 * ty + dy) * W + xx) * Co + c4 * 4) = v;
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Fused Winograd GEMM + output transform.  Block = 128 tiles x 64 channels, 4 waves as 2(M) x 2(N),
-// wave tile 64 x 32 (two 32x32 MFMA tiles); per wave 32 product registers + 4 x 32 output
-// registers, so two blocks share a CU.  LDS is double buffered (one barrier per K step of 32).
-// The 16 components run as one flat loop of 16 * Cin/32 steps; the loader runs one step ahead and
-// simply walks into the next component.  After the last K step of component (a,b) the product is
-// added into output (i,j) with coefficient AT[i][a] * AT[j][b] (0 / +-1, exact as an fma).
-// Block order: hardware deals consecutive block ids round-robin over the 8 XCDs, so the logical
-// tile id is (id % 8) * chunk + id / 8 -- the N-blocks that share a V tile then sit on one XCD's L2.
-// ---------------------------------------------------------------------------
-constexpr int WBM = 128, WBN = 64, WBUF = (WBM + WBN) * LDT;
-
-// component (a,b) = comp complete: o[i][j] += AT[i][a] * AT[j][b] * acc (coefficients 0 / +-1, exact
-// as an fma; wave-uniform branches: 7 of the 16 components touch one output only, 4 touch all four)
-template <int MT>
-__device__ __forceinline__ void wino_flush(f32x16 (&acc)[MT], f32x16 (&o)[2][2][MT], int& kc, int& comp) {
-  const int ka = comp >> 2, kb = comp & 3;
-  const float ra0 = ka < 3 ? 1.f : 0.f, ra1 = ka == 0 ? 0.f : (ka == 1 ? 1.f : -1.f);
-  const float cb0 = kb < 3 ? 1.f : 0.f, cb1 = kb == 0 ? 0.f : (kb == 1 ? 1.f : -1.f);
-  const float c00 = ra0 * cb0, c01 = ra0 * cb1, c10 = ra1 * cb0, c11 = ra1 * cb1;
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const float c = i ? (j ? c11 : c10) : (j ? c01 : c00);
-      if (c != 0.f) {
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) o[i][j][mt][r] = __builtin_fmaf(c, acc[mt][r], o[i][j][mt][r]);
-      }
-    }
-#pragma unroll
-  for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
-  kc = 0;
-  comp++;
-}
-
-// bias + activation + width mask, NHWC (or the max over the tile when pooling)
-template <int MT>
-__device__ __forceinline__ void wino_epilogue(const f32x16 (&o)[2][2][MT], const WinoGemm& p, int m0, int n0, int wm,
-                                              int wn, int lane) {
-  const int th = p.H >> 1, tw = (p.W + 1) >> 1;
-  const int n = n0 + wn * 32 + (lane & 31);
-  const float bias = p.bias[n];
-  const int act = p.act;
-  auto activate = [&](float v) {
-    const float neg = act == 2 ? 0.2f * v : (act == 1 ? 0.f : v);
-    return v > 0.f ? v : neg;
-  };
-  // tile -> (line, tile row, tile column): one reciprocal-multiply division per group of four
-  // consecutive tiles (exact for t < 2^24 with the +-1 fix-up), then carry increments
-  const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
-  auto divmod = [](int t, int d, float inv, int& q, int& r) {
-    q = (int)((float)t * inv);
-    r = t - q * d;
-    if (r < 0) { q--; r += d; }
-    if (r >= d) { q++; r -= d; }
-  };
-#pragma unroll
-  for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-    for (int rq = 0; rq < 4; rq++) {
-      const int t0 = m0 + wm * (32 * MT) + mt * 32 + 8 * rq + 4 * (lane >> 5);
-      int q, tx, b, ty;
-      divmod(t0, tw, inv_tw, q, tx);
-      divmod(q, th, inv_th, b, ty);
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int r = rq * 4 + rr;
-        if (t0 + rr < p.m_off + p.m_cnt) {
-          const int wv = p.wvalid ? p.wvalid[b] : p.W;
-          float v[2][2];
-#pragma unroll
-          for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-              const float e = activate(o[i][j][mt][r] + bias);
-              v[i][j] = (2 * tx + j < wv) ? e : 0.f;
-            }
-          if (p.pool) {
-            if (tx < (p.W >> 1)) {   // odd W: the last column has no pool window
-              const float mx = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
-              p.y[(((long)b * th + ty) * (p.W >> 1) + tx) * p.N + n] = mx;
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-              for (int j = 0; j < 2; j++)
-                if (2 * tx + j < p.W) p.y[(((long)b * p.H + 2 * ty + i) * p.W + 2 * tx + j) * p.N + n] = v[i][j];
-          }
-        }
-        // next tile in (line, row, column) order
-        tx++;
-        const bool cx = tx == tw;
-        tx = cx ? 0 : tx;
-        ty += cx ? 1 : 0;
-        const bool cy = ty == th;
-        ty = cy ? 0 : ty;
-        b += cy ? 1 : 0;
-      }
-    }
-}
-
-
-__global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoGemm p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * WBUF];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = p.N / WBN;
-  const int nblk = ((p.ntile + WBM - 1) / WBM) * ntn;
-  const int chunk = gridDim.x >> 3;
-  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (L >= nblk) return;
-  const int bm = L / ntn, bn = L - bm * ntn;
-  const int m0 = bm * WBM, n0 = bn * WBN;
-  const int lrow = tid >> 3, lk = (tid & 7) * 4;
-
-  unsigned aoff[4], boff[2];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int m = m0 + lrow + 32 * i;
-    m = m < p.ntile ? m : p.ntile - 1;
-    aoff[i] = (unsigned)(((long)m * p.Cin + lk) * 4);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; i++) boff[i] = (unsigned)(((long)(n0 + lrow + 32 * i) * p.Cin + lk) * 4);
-  const long bsA = (long)p.ntile * p.Cin, bsW = (long)p.N * p.Cin;
-  const int nk = p.Cin / BK;
-
-  // two register sets: the loader runs two K steps ahead (one step of MFMAs per wave is only
-  // ~2 us at two waves per SIMD, not enough to cover an HBM miss)
-  f32x4 ra[2][4], rb[2][2];
-  int l_comp = 0, l_k0 = 0;   // position of the next K step to load (wave uniform)
-  auto gload = [&](int set) {
-    const __amdgpu_buffer_rsrc_t a_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + l_comp * bsA), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t b_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.U + l_comp * bsW), 0, 0x7FFFFFFF, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      ra[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, aoff[i], l_k0 * 4, 0));
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-      rb[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, boff[i], l_k0 * 4, 0));
-    // past the last step the loader just re-reads component 15 (never stored to a buffer that is
-    // read): the loop body then has no branch around a load, so the compiler can wait for the older
-    // register set only (vmcnt(6)) instead of draining both
-    l_k0 += BK;
-    const bool wrap = l_k0 == p.Cin;
-    l_k0 = wrap ? 0 : l_k0;
-    l_comp += (wrap && l_comp < 15) ? 1 : 0;
-  };
-  auto sstore = [&](int set, int buf) {
-    float* sa = smem + buf * WBUF;
-    float* sb = sa + WBM * LDT;
-#pragma unroll
-    for (int i = 0; i < 4; i++) *(f32x4*)(sa + (lrow + 32 * i) * LDT + lk) = ra[set][i];
-#pragma unroll
-    for (int i = 0; i < 2; i++) *(f32x4*)(sb + (lrow + 32 * i) * LDT + lk) = rb[set][i];
-  };
-
-  f32x16 acc[2], o[2][2][2];   // o[i][j][mt]: output (2ty+i, 2tx+j) of the tiles in MFMA tile mt
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    acc[0][r] = 0.f; acc[1][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) { o[i][j][0][r] = 0.f; o[i][j][1][r] = 0.f; }
-  }
-  // fragments of k-group g+1 are read while the 8 MFMAs of k-group g run (two fragment sets)
-  auto compute = [&](int buf) {
-    const float* a = smem + buf * WBUF + (wm * 64 + (lane & 31)) * LDT + 4 * (lane >> 5);
-    const float* b = smem + buf * WBUF + WBM * LDT + (wn * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
-    f32x4 a0[2], a1[2], b0[2];
-    a0[0] = *(const f32x4*)(a);
-    a1[0] = *(const f32x4*)(a + 32 * LDT);
-    b0[0] = *(const f32x4*)(b);
-#pragma unroll
-    for (int kg = 0; kg < 4; kg++) {
-      const int c = kg & 1;
-      if (kg < 3) {
-        a0[c ^ 1] = *(const f32x4*)(a + (kg + 1) * 8);
-        a1[c ^ 1] = *(const f32x4*)(a + 32 * LDT + (kg + 1) * 8);
-        b0[c ^ 1] = *(const f32x4*)(b + (kg + 1) * 8);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c][j], b0[c][j], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c][j], b0[c][j], acc[1], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  int kc = 0, comp = 0;
-  auto flush = [&]() { wino_flush<2>(acc, o, kc, comp); };
-  // steps are numbered 0 .. nit-1 (nit is even); step s is staged through register set s & 1 and
-  // LDS buffer s & 1.  Entering iteration `it`: LDS holds step it, set (it+1)&1 holds / is
-  // receiving step it+1, and step it+2 is issued into the other set as soon as that set was stored.
-  const int nit = 16 * nk;
-  gload(0);
-  sstore(0, 0);
-  gload(1);
-  gload(0);
-  __syncthreads();
-#pragma unroll 1
-  for (int it = 0; it < nit; it += 2) {
-    compute(0);
-    sstore(1, 1);      // step it+1 (its loads were issued two steps ago)
-    gload(1);          // step it+3
-    __syncthreads();
-    if (++kc == nk) flush();
-    compute(1);
-    sstore(0, 0);      // step it+2
-    gload(0);          // step it+4
-    __syncthreads();
-    if (++kc == nk) flush();
-  }
-
-  wino_epilogue<2>(o, p, m0, n0, wm, wn, lane);
-}
-
-// ---------------------------------------------------------------------------
-// Same computation, operands staged with direct-to-LDS loads (buffer_load_dwordx4 ... lds): no
-// staging VGPRs and no ds_write; three unpadded 24 KB stages per block (two blocks per CU), loads
-// run two-plus steps ahead.  A wave-level load writes 1 KiB contiguously (lane l -> base + 16 l),
-// i.e. eight 128-byte rows back to back, so instead of padding rows the 16-byte k-chunks are
-// XOR-swizzled inside 256-byte row pairs: chunk position = ((row & 1) * 8 + kchunk) ^ ((row >> 1) & 15).
-// Each lane simply fetches the global chunk that belongs at its LDS position; the 16 lanes of a
-// fragment-read phase (16 consecutive rows, one k-chunk) then hit 16 distinct 16-byte bank groups.
-// The barrier that publishes step s+1 sits before the last k-group of step s, so its wait and
-// the first fragment reads of the next step run under 8 MFMAs.
+// Operand staging of every GEMM kernel below: direct-to-LDS loads (buffer_load_dwordx4 ... lds): no staging VGPRs and
+// no ds_write.  A wave-level load writes 1 KiB contiguously (lane l -> base + 16 l), i.e. eight 128-byte rows back to
+// back, so instead of padding rows the 16-byte k-chunks are XOR-swizzled inside 256-byte row pairs: chunk position =
+// ((row & 1) * 8 + kchunk) ^ ((row >> 1) & 15).  Each lane simply fetches the global chunk that belongs at its LDS
+// position; the 16 lanes of a fragment-read phase (16 consecutive rows, one k-chunk) then hit 16 distinct 16-byte bank
+// groups (SQ_LDS_BANK_CONFLICT = 0).  (Round 1's F(2x2,3x3) kernels, where this staging was first built, and the
+// register-staged form before it are gone: the F(4x4) kernels below won at every batch size; DESIGN.md, history.)
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// NWN = waves along N: 2 -> 128 x 64 tile, 256 threads, two blocks per CU; 4 -> 128 x 128 tile, 512 threads,
-// one block per CU (a third fewer loads per MFMA, half the L2 -> LDS traffic).
-// MT = 32-row MFMA tiles per wave along M: 2 -> 128-tile blocks; 1 -> 64 x 64 blocks with 80 accumulator
-// registers per lane, three blocks (12 waves) per CU and four times as many, smaller work units.
-template <int NWN, int MT>
-__global__ __launch_bounds__(128 * NWN, MT == 1 ? 3 : (NWN == 2 ? 2 : 1)) void wino_gemm_dma_kernel(const WinoGemm p) {
-  // threads, tile M / N, floats per A / B stage, A loads per thread
-  constexpr int NT = 128 * NWN, TBM = 64 * MT, TBN = 32 * NWN, SA = TBM * 32, SB = TBN * 32, NLA = TBM * 8 / NT;
-  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];   // [B0 B1 B2 | A0 A1 A2], 72 / 96 KB
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / NWN, wn = wave % NWN;
-  const int ntn = p.N / TBN;
-  const int nblk = ((p.m_cnt + TBM - 1) / TBM) * ntn;
-  const int chunk = gridDim.x >> 3;
-  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (L >= nblk) return;
-  const int bm = L / ntn, bn = L - bm * ntn;
-  const int m0 = p.m_off + bm * TBM, n0 = bn * TBN;
-
-  // loader: LDS chunk position P = i * 256 + tid holds (row, kchunk) given by the swizzle
-  unsigned aoff[NLA], boff[2];
-#pragma unroll
-  for (int i = 0; i < NLA; i++) {
-    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
-    int m = m0 + 2 * S + (c16 >> 3);
-    m = m < p.ntile ? m : p.ntile - 1;
-    aoff[i] = (unsigned)(((long)m * p.Cin + (c16 & 7) * 4) * 4);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
-    boff[i] = (unsigned)(((long)(n0 + 2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
-  }
-  const long bsA = (long)p.ntile * p.Cin, bsW = (long)p.N * p.Cin;
-  const int nk = p.Cin / BK;
-  int l_comp = 0, l_k0 = 0;   // position of the next K step to load (wave uniform)
-  // The loads are issued from inline asm: the compiler then keeps no vmcnt bookkeeping for them
-  // (it cannot tell the stages apart and would drain every load before each fragment read); the
-  // waits below are written by hand.
-  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;   // bytes, wave uniform
-  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) {
-    unsigned m0_saved;   // M0 is restored: the compiler may keep a value of its own there (clobbering it is not allowed)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-  };
-  // running descriptor bases (bytes): advance by one component when the K position wraps
-  unsigned long long pa = (unsigned long long)p.V, pb = (unsigned long long)p.U;
-  const unsigned long long stepA = (unsigned long long)bsA * 4, stepB = (unsigned long long)bsW * 4;
-  auto gload = [&](int stage) {
-    const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
-    const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
-    const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
-#pragma unroll
-    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], l_k0 * 4);
-#pragma unroll
-    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * NT * 16, boff[i], l_k0 * 4);
-    // past the last step the loader re-reads component 15 into a stage nobody reads any more
-    l_k0 += BK;
-    const bool wrap = l_k0 == p.Cin;
-    l_k0 = wrap ? 0 : l_k0;
-    const bool adv = wrap && l_comp < 15;
-    l_comp += adv ? 1 : 0;
-    pa += adv ? stepA : 0;
-    pb += adv ? stepB : 0;
-  };
-
-  // fragment addresses (floats, inside a stage) per k-group; a1 = a0 + 32 rows = + 1024 floats
-  int aaddr[4], baddr[4];
-  {
-    const int Ra = wm * (32 * MT) + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
-#pragma unroll
-    for (int kg = 0; kg < 4; kg++) {
-      aaddr[kg] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (2 * kg + h)) ^ ((Ra >> 1) & 15)) << 2);
-      baddr[kg] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (2 * kg + h)) ^ ((Rb >> 1) & 15)) << 2);
-    }
-  }
-
-  f32x16 acc[MT], o[2][2][MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      acc[mt][r] = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) o[i][j][mt][r] = 0.f;
-    }
-  int kc = 0, comp = 0;
-  f32x4 a0[2], a1[2], b0[2];
-  auto frag = [&](int stage, int kg, int set) {
-    const float* sa = smem + 3 * SB + stage * SA;
-    const float* sb = smem + stage * SB;
-    a0[set] = *(const f32x4*)(sa + aaddr[kg]);
-    if (MT == 2) a1[set] = *(const f32x4*)(sa + aaddr[kg] + 1024);
-    b0[set] = *(const f32x4*)(sb + baddr[kg]);
-  };
-  auto mfma8 = [&](int set) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[set][j], b0[set][j], acc[0], 0, 0, 0);
-      if (MT == 2) acc[MT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[set][j], b0[set][j], acc[MT - 1], 0, 0, 0);
-    }
-  };
-  // one K step on stage st; on entry fragment set 0 holds k-group 0 of this step
-  auto step = [&](auto ST) {
-    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
-    frag(st, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(0);
-    __builtin_amdgcn_sched_barrier(0);
-    frag(st, 2, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(1);
-    __builtin_amdgcn_sched_barrier(0);
-    frag(st, 3, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(0);
-    __builtin_amdgcn_sched_barrier(0);
-    // publish the next step: its 6 loads were issued two steps ago (the 6 of the step after it may
-    // still be in flight); every wave has read all of stage st into registers by now
-    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // vmcnt(one step's loads) lgkmcnt(0)
-    __syncthreads();
-    gload(st);                            // step +3 reuses this stage
-    frag(nx, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (++kc == nk) wino_flush<MT>(acc, o, kc, comp);
-  };
-
-  const int nit = 16 * nk;
-  gload(0);
-  gload(1);
-  gload(2);
-  constexpr int LPS = NLA + 2;               // loads per K step per wave (4 or 6)
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));   // vmcnt(2 steps' loads): step 0 landed
-  __syncthreads();
-  frag(0, 0, 0);
-  int it = 0;
-#pragma unroll 1
-  for (; it + 3 <= nit; it += 3) {
-    step(std::integral_constant<int, 0>{});
-    step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{});
-  }
-  if (it < nit) step(std::integral_constant<int, 0>{});
-  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
-  __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): no LDS write may be in flight when the block ends
-  wino_epilogue<MT>(o, p, m0, n0, wm, wn, lane);
-}
-
-// one launch of one tile shape (0 register-staged 128x64, 1 DMA 128x64, 2 DMA 128x128, 3 DMA 64x64) over the
-// Winograd tiles [m_off, m_off + m_cnt)
-static void launch_wino_shape(WinoGemm q, int shape, int m_off, int m_cnt, hipStream_t s) {
-  q.m_off = m_off; q.m_cnt = m_cnt;
-  if (shape == 2 && q.N % 128) shape = 1;
-  const int tbm = shape == 3 ? 64 : 128, tbn = shape == 2 ? 128 : 64;
-  const int units = ((m_cnt + tbm - 1) / tbm) * (q.N / tbn);
-  const dim3 g(8 * ((units + 7) / 8));
-  if (shape == 3) hipLaunchKernelGGL((wino_gemm_dma_kernel<2, 1>), g, dim3(256), 0, s, q);
-  else if (shape == 2) hipLaunchKernelGGL((wino_gemm_dma_kernel<4, 2>), g, dim3(512), 0, s, q);
-  else if (shape == 1) hipLaunchKernelGGL((wino_gemm_dma_kernel<2, 2>), g, dim3(256), 0, s, q);
-  else hipLaunchKernelGGL(wino_gemm_kernel, g, dim3(256), 0, s, q);
-}
-
-// Tile shapes.  128x128 (512 threads, one block per CU, 256 slots) has the fewest loads per MFMA and is the
-// fastest while it fills its rounds (MfmaUtil 0.85-0.88 inside a round), but a partly filled last round costs
-// it all of that round's emptiness: at batch 256 its 576 tiles of conv5 are 2.25 rounds.  So the full rounds go
-// to the 128x128 shape and the remaining tiles to a second launch with a small shape whose units spread over
-// all CUs -- 64x64 (three blocks per CU) for up to 384 128x64-units' worth, 128x64 beyond (and 128x128 again if
-// they fill 85 % of a round).  Without a full
-// 128x128 round (small batches) one launch of the shape with the best estimate  peak * (1 - tail * (1 - fill)),
-// fill = units / (rounds * slots), peak 1.0 / 0.94 and tail 1/3 for 128x64 (512 slots) / 64x64 (768 slots).
-// CRNN_WINO_DMA = 0..3 forces one shape for everything (tests/test_hip_variants.py runs them all).
-void launch_wino_gemm(const WinoGemm& p, hipStream_t s) {
-  static const int dma = getenv("CRNN_WINO_DMA") ? atoi(getenv("CRNN_WINO_DMA")) : -1;
-  if (dma >= 0) { launch_wino_shape(p, dma > 3 ? 1 : dma, 0, p.ntile, s); return; }
-  if (p.N % 128 == 0) {
-    const int per_round = (256 / (p.N / 128)) * 128;        // tiles one full round of 128x128 blocks covers
-    const int full = (p.ntile / per_round) * per_round;
-    if (full > 0) {
-      launch_wino_shape(p, 2, 0, full, s);
-      const int rem = p.ntile - full;
-      if (rem > 0) {
-        const int u1 = ((rem + 127) / 128) * (p.N / 64);
-        // an almost full round stays with the big shape
-        launch_wino_shape(p, rem * 100 >= per_round * 85 ? 2 : (u1 <= 384 ? 3 : 1), full, rem, s);
-      }
-      return;
-    }
-    if (p.ntile * 100 >= per_round * 85) { launch_wino_shape(p, 2, 0, p.ntile, s); return; }
-  }
-  const int units[4] = {0, ((p.ntile + 127) / 128) * (p.N / 64), 0, ((p.ntile + 63) / 64) * (p.N / 64)};
-  const int slots[4] = {0, 512, 0, 768};
-  const double peak[4] = {0, 1.0, 0, 0.94};
-  int shape = 1;
-  double best = 0;
-  // less than one round of 128x64 blocks: latency-bound, and the 64x64 shape halves the MFMA chain per wave
-  // and per K step (n = 1: conv1-5 0.71 -> 0.40 ms; equal or better up to ~96 lines)
-  if (units[1] <= 512) { launch_wino_shape(p, 3, 0, p.ntile, s); return; }
-  for (int k = 1; k <= 3; k += 2) {
-    const double fill = (double)units[k] / ((double)((units[k] + slots[k] - 1) / slots[k]) * slots[k]);
-    const double est = peak[k] * (1.0 - (1.0 - fill) / 3.0);
-    if (est > best) { best = est; shape = k; }
-  }
-  launch_wino_shape(p, shape, 0, p.ntile, s);
-}
 
 static unsigned ew_blocks_w(long total) {
   long b = (total + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
   if (b < 1) b = 1;
   return (unsigned)b;
-}
-
-void launch_wino_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s) {
-  const long total = (long)B * ((W + 1) / 2) * (C / 4);
-  hipLaunchKernelGGL(wino_in_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, x, V, B, H, W, C);
-}
-void launch_wino_out(const float* Mo, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
-                     int Cout, int act, hipStream_t s) {
-  const long total = (long)B * (H / 2) * ((W + 1) / 2) * (Cout / 4);
-  hipLaunchKernelGGL(wino_out_kernel, dim3(ew_blocks_w(total)), dim3(256), 0, s, Mo, bias, y, wvalid, B, H, W,
-                     Cout, act);
 }
 
 // (wino4_bt / wino4_at and the f16x3 split helpers are in crnn_split.h, shared with crnn_kernels_nopk.hip)
@@ -1043,169 +477,10 @@ __global__ __launch_bounds__(256) void wino4_out_pool21_kernel(const float* __re
 // last round -- and at any moment the blocks work on G consecutive units, i.e. on one or two components, so
 // the U slice and the V tiles that several units share are L2 hits (the XCD-aware block order keeps the units
 // that share a V tile on one XCD).  Inside a block the K steps of all its units form one flat loop over the
-// same three-stage direct-to-LDS pipeline as wino_gemm_dma_kernel: the loader walks into the next unit while
+// same three-stage direct-to-LDS pipeline: the loader walks into the next unit while
 // the MFMAs finish the current one, whose product is stored straight from the accumulators.
-template <int NWN>
-__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void wino4_gemm_kernel(const Wino4Gemm p) {
-  constexpr int NT = 128 * NWN, TBM = 128, TBN = 32 * NWN, SA = TBM * 32, SB = TBN * 32, NLA = TBM * 8 / NT;
-  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];   // [B0 B1 B2 | A0 A1 A2]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / NWN, wn = wave % NWN;
-  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
-  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
-  const int chunk = G >> 3;
-  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (L >= NU) return;
-  const int my_units = (NU - L + G - 1) / G;
-
-  unsigned aoff[NLA], boff[2];
-#pragma unroll
-  for (int i = 0; i < NLA; i++) {
-    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
-    aoff[i] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
-    boff[i] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
-  }
-  const int nk = p.Cin / BK;
-  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;
-  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) {
-    unsigned m0_saved;   // M0 is restored: the compiler may keep a value of its own there (clobbering it is not allowed)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-  };
-  // unit -> operand bases (wave uniform)
-  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) {
-    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
-    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.Cin * 4ull;
-    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.Cin * 4ull;
-    m = (unsigned long long)p.M +
-        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
-  };
-  int l_u = L, l_k0 = 0;
-  unsigned long long pa, pb, pm_unused;
-  bases(l_u, pa, pb, pm_unused);
-  auto gload = [&](int stage) {
-    const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
-    const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
-    const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
-#pragma unroll
-    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], l_k0 * 4);
-#pragma unroll
-    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * NT * 16, boff[i], l_k0 * 4);
-    l_k0 += BK;
-    if (l_k0 == p.Cin) {   // next unit of this block (past the last one: re-read it into a stage nobody reads)
-      l_k0 = 0;
-      if (l_u + G < NU) l_u += G;
-      unsigned long long pm;
-      bases(l_u, pa, pb, pm);
-    }
-  };
-
-  int aaddr[4], baddr[4];
-  {
-    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
-#pragma unroll
-    for (int kg = 0; kg < 4; kg++) {
-      aaddr[kg] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (2 * kg + h)) ^ ((Ra >> 1) & 15)) << 2);
-      baddr[kg] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (2 * kg + h)) ^ ((Rb >> 1) & 15)) << 2);
-    }
-  }
-  f32x16 acc[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
-  int kc = 0, c_u = L;
-  // The MFMAs take the U fragment as their first operand, so the product sits transposed in the accumulators:
-  // lane & 31 = tile (row of M), register r = channel 8 (r >> 2) + 4 half + (r & 3) -- a lane owns four
-  // consecutive channels of one row per register quad and stores them as 16 bytes (8 stores per unit and wave
-  // instead of 32: the stores share the memory pipeline and vmcnt with the operand loads).
-  const unsigned moff = (unsigned)((wm * 64 + (lane & 31)) * p.N + wn * 32 + 4 * (lane >> 5));
-  auto flush = [&]() __attribute__((always_inline)) {
-    unsigned long long ua, ub, pm;
-    bases(c_u, ua, ub, pm);
-    // global address space spelled out: a pointer made from an integer is generic, and FLAT stores also count
-    // in lgkmcnt, where the very next fragment-read wait would stall on them
-    typedef __attribute__((address_space(1))) f32x4 gf32x4;
-    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-        *(gf32x4*)(dst + mt * 32 * p.N + 8 * g) = v;
-#pragma unroll
-        for (int e = 0; e < 4; e++) acc[mt][4 * g + e] = 0.f;
-      }
-    kc = 0;
-    c_u += G;
-  };
-
-  f32x4 a0[2], a1[2], b0[2];
-  auto frag = [&](int stage, int kg, int set) {
-    const float* sa = smem + 3 * SB + stage * SA;
-    const float* sb = smem + stage * SB;
-    a0[set] = *(const f32x4*)(sa + aaddr[kg]);
-    a1[set] = *(const f32x4*)(sa + aaddr[kg] + 1024);
-    b0[set] = *(const f32x4*)(sb + baddr[kg]);
-  };
-  auto mfma8 = [&](int set) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[set][j], a0[set][j], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[set][j], a1[set][j], acc[1], 0, 0, 0);
-    }
-  };
-  auto step = [&](auto ST) {
-    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
-    frag(st, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(0);
-    __builtin_amdgcn_sched_barrier(0);
-    frag(st, 2, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(1);
-    __builtin_amdgcn_sched_barrier(0);
-    frag(st, 3, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(0);
-    __builtin_amdgcn_sched_barrier(0);
-    // the next step's loads were issued two steps ago; loads return in order among themselves, so at most one
-    // step's worth of outstanding operations (product stores of a flush included) means they have landed
-    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));
-    __syncthreads();
-    gload(st);
-    frag(nx, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (++kc == nk) flush();
-  };
-
-  const int nit = my_units * nk;
-  gload(0);
-  gload(1);
-  gload(2);
-  constexpr int LPS = NLA + 2;
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));
-  __syncthreads();
-  frag(0, 0, 0);
-  int it = 0;
-#pragma unroll 1
-  for (; it + 3 <= nit; it += 3) {
-    step(std::integral_constant<int, 0>{});
-    step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{});
-  }
-  if (it < nit) step(std::integral_constant<int, 0>{});
-  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
-  __builtin_amdgcn_s_waitcnt(0x0F70);     // no LDS write may be in flight when the block ends
-}
-
-// Same computation with a dedicated LOADER WAVE: a ninth wave issues all direct-to-LDS operand loads of the
+// The kernel (f32 MFMA form; the version in which every wave issued its share of the loads is gone) has a dedicated
+// LOADER WAVE: a ninth wave issues all direct-to-LDS operand loads of the
 // block (32 per K step) and is the only one that waits on vmcnt; the eight MFMA waves only read fragments,
 // issue MFMAs and store finished products -- their stores no longer sit in the counter the operand pipeline
 // waits on, and they issue no load instructions at all.  One barrier per K step, executed by all nine waves:
@@ -1372,165 +647,18 @@ __global__ __launch_bounds__(576, 1) void wino4_gemm_lw_kernel(const Wino4Gemm p
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------------------
 // The Winograd component GEMMs on operands in the f16x3 format (see wino4_in_h3_kernel): same persistent balanced-unit
-// structure, unit order, three-stage direct-to-LDS pipeline, LDS layout and swizzle as wino4_gemm_kernel<4> -- a row's
+// structure, unit order, three-stage direct-to-LDS pipeline, LDS layout and swizzle as wino4_gemm_lw_kernel -- a row's
 // K = 32 step is still 128 bytes = 8 chunks of 16 bytes, now hi(k0-7) lo(k0-7) hi(k8-15) lo(k8-15) ... -- but a K step
 // is two k16 MFMA steps of three products each (lo hi, hi lo, hi hi into one accumulator): 12 MFMAs of 32 cycles per wave
 // and K step instead of 32 of 64.  The products leave scaled by s_tile s_weights; the output transform undoes that.
-// 128 x 128 units, 8 waves as 2 (M) x 4 (N), wave tile 64 x 32; every wave issues its share of the loads (2 + 2 per step).
+// 128 x 128 units, 8 waves as 2 (M) x 4 (N), wave tile 64 x 32.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void wino4_gemm_h3_kernel(const Wino4Gemm p) {
-  constexpr int NWN = 4, NT = 512, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32, NLA = 2;
-  __shared__ __attribute__((aligned(1024))) float smem[3 * (SA + SB)];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / NWN, wn = wave % NWN;
-  const int ntn = p.N / TBN, ntm = p.ntile_pad / TBM;
-  const int NU = p.ncomp * ntm * ntn, G = gridDim.x;
-  const int chunk = G >> 3;
-  const int L = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (L >= NU) return;
-  const int my_units = (NU - L + G - 1) / G;
-  unsigned aoff[NLA], boff[2];
-#pragma unroll
-  for (int i = 0; i < NLA; i++) {
-    const int P = i * NT + tid, S = P >> 4, c16 = (P & 15) ^ (S & 15);
-    aoff[i] = (unsigned)(((2 * S + (c16 >> 3)) * p.Cin + (c16 & 7) * 4) * 4);
-    boff[i] = aoff[i];
-  }
-  const int nk = p.Cin / BK;
-  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem + (unsigned)wave * 1024u;
-  auto dma = [&](i32x4 rsrc, unsigned ldsaddr, unsigned voff, int soff) __attribute__((always_inline)) {
-    unsigned m0_saved;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(m0_saved) : "s"(ldsaddr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-  };
-  auto bases = [&](int u, unsigned long long& a, unsigned long long& b, unsigned long long& m) __attribute__((always_inline)) {
-    const int nt = u % ntn, q = u / ntn, mt = q % ntm, comp = q / ntm;
-    a = (unsigned long long)p.V + ((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.Cin * 4ull;
-    b = (unsigned long long)p.U + ((unsigned long long)comp * p.N + (unsigned long long)nt * TBN) * p.Cin * 4ull;
-    m = (unsigned long long)p.M +
-        (((unsigned long long)comp * p.ntile_pad + (unsigned long long)mt * TBM) * p.N + (unsigned long long)nt * TBN) * 4ull;
-  };
-  int l_u = L, l_k0 = 0;
-  unsigned long long pa, pb, pm_unused;
-  bases(l_u, pa, pb, pm_unused);
-  auto gload = [&](int stage) __attribute__((always_inline)) {
-    const i32x4 a_rsrc = {(int)(unsigned)pa, (int)((pa >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
-    const i32x4 b_rsrc = {(int)(unsigned)pb, (int)((pb >> 32) & 0xFFFF), 0x7FFFFFFF, 0x00020000};
-    const unsigned sa = lds0 + (3 * SB + stage * SA) * 4, sb = lds0 + stage * SB * 4;
-#pragma unroll
-    for (int i = 0; i < NLA; i++) dma(a_rsrc, sa + i * NT * 16, aoff[i], l_k0 * 4);
-#pragma unroll
-    for (int i = 0; i < 2; i++) dma(b_rsrc, sb + i * NT * 16, boff[i], l_k0 * 4);
-    l_k0 += BK;
-    if (l_k0 == p.Cin) {
-      l_k0 = 0;
-      if (l_u + G < NU) l_u += G;
-      unsigned long long pm;
-      bases(l_u, pa, pb, pm);
-    }
-  };
-  // fragment addresses (floats inside a stage): chunk c of row R sits at (R >> 1) * 64 + ((((R & 1) << 3) | c) ^ ((R >> 1) & 15)) * 4;
-  // k16-step j of a K = 32 step: hi = chunk 4 j + 2 h, lo = the chunk after it (h = lane >> 5)
-  int ahi[2], alo[2], bhi[2], blo[2];
-  {
-    const int Ra = wm * 64 + (lane & 31), Rb = wn * 32 + (lane & 31), h = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int c = 4 * j + 2 * h;
-      ahi[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | c) ^ ((Ra >> 1) & 15)) << 2);
-      alo[j] = (Ra >> 1) * 64 + (((((Ra & 1) << 3) | (c + 1)) ^ ((Ra >> 1) & 15)) << 2);
-      bhi[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | c) ^ ((Rb >> 1) & 15)) << 2);
-      blo[j] = (Rb >> 1) * 64 + (((((Rb & 1) << 3) | (c + 1)) ^ ((Rb >> 1) & 15)) << 2);
-    }
-  }
-  f32x16 acc[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
-  int kc = 0, c_u = L;
-  const unsigned moff = (unsigned)((wm * 64 + (lane & 31)) * p.N + wn * 32 + 4 * (lane >> 5));
-  auto flush = [&]() __attribute__((always_inline)) {
-    unsigned long long ua, ub, pm;
-    bases(c_u, ua, ub, pm);
-    typedef __attribute__((address_space(1))) f32x4 gf32x4;
-    __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-#ifdef H3_NOSTORE
-        if (v[0] == 12345.f)
-#endif
-        *(gf32x4*)(dst + mt * 32 * p.N + 8 * g) = v;   // (nontemporal product stores: 20 % slower, measured)
-#pragma unroll
-        for (int e = 0; e < 4; e++) acc[mt][4 * g + e] = 0.f;
-      }
-    kc = 0;
-    c_u += G;
-  };
-  f16x8 a0h[2], a0l[2], a1h[2], a1l[2], bh[2], bl[2];
-  auto frag = [&](int stage, int j, int set) __attribute__((always_inline)) {
-    const float* sa = smem + 3 * SB + stage * SA;
-    const float* sb = smem + stage * SB;
-    a0h[set] = *(const f16x8*)(sa + ahi[j]);
-    a0l[set] = *(const f16x8*)(sa + alo[j]);
-    a1h[set] = *(const f16x8*)(sa + ahi[j] + 1024);
-    a1l[set] = *(const f16x8*)(sa + alo[j] + 1024);
-    bh[set] = *(const f16x8*)(sb + bhi[j]);
-    bl[set] = *(const f16x8*)(sb + blo[j]);
-  };
-  auto mfma6 = [&](int set) __attribute__((always_inline)) {
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[set], a0h[set], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[set], a1h[set], acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a0l[set], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a1l[set], acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a0h[set], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[set], a1h[set], acc[1], 0, 0, 0);
-  };
-  auto step = [&](auto ST) __attribute__((always_inline)) {
-    constexpr int st = decltype(ST)::value, nx = (st + 1) % 3;
-    frag(st, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma6(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // vmcnt(one step's loads), lgkmcnt(0)
-    __syncthreads();
-    gload(st);
-    frag(nx, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma6(1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (++kc == nk) flush();
-  };
-  const int nit = my_units * nk;
-  gload(0);
-  gload(1);
-  gload(2);
-  constexpr int LPS = NLA + 2;
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * LPS));
-  __syncthreads();
-  frag(0, 0, 0);
-  int it = 0;
-#pragma unroll 1
-  for (; it + 3 <= nit; it += 3) {
-    step(std::integral_constant<int, 0>{});
-    step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{});
-  }
-  if (it < nit) step(std::integral_constant<int, 0>{});
-  if (it + 1 < nit) step(std::integral_constant<int, 1>{});
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-}
-
-
-// The same kernel with NLW dedicated loader waves (waves 8 .. 8 + NLW - 1, as in wino4_gemm_lw_kernel): they issue all
+// NLW dedicated loader waves (waves 8 .. 8 + NLW - 1, as in wino4_gemm_lw_kernel): they issue all
 // direct-to-LDS loads of the block (32 per K step) and are the only waves that wait on vmcnt; the eight MFMA waves read
 // fragments, issue MFMAs and store finished products.  One barrier per K step, executed by all waves.  With the MFMA
 // phase of a step only 384 cycles per wave, one loader wave cannot issue 32 loads in time: four do (8 each).  Measured
-// against the form above (tools/h3_gemm_bench.hip): -9 % at K = 512, -4..6 % at K = 256 and K = 1024, +5 % at K = 64
-// (conv1, which is HBM-bound on its product tensor), so it is used from K = 256.
+// against the form in which every wave loads its share (tools/h3_gemm_bench.hip): -9 % at K = 512, -4..6 % at K = 256 and
+// K = 1024, +5 % at K = 64 (conv1, which is HBM-bound on its product tensor and runs on the fused kernel below anyway).
 template <int NLW>
 __global__ __launch_bounds__(512 + 64 * NLW, 1) void wino4_gemm_h3_lw_kernel(const Wino4Gemm p) {
   constexpr int NWN = 4, TBM = 128, TBN = 128, SA = TBM * 32, SB = TBN * 32, QW = 16 / NLW;
@@ -2356,7 +1484,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
     __builtin_amdgcn_sched_barrier(0);
     mfma8(0);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // see wino4_gemm_kernel
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // vmcnt(one step's loads), lgkmcnt(0)
     __syncthreads();
     gload(st);
     frag(nx, 0, 0);
@@ -2553,7 +1681,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_h3_kernel(const ConvGemm p) {
     __builtin_amdgcn_sched_barrier(0);
     mfma6(0);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // see wino4_gemm_kernel
+    __builtin_amdgcn_s_waitcnt(0x0070 | (NLA + 2));   // vmcnt(one step's loads), lgkmcnt(0)
     __syncthreads();
     gload(st);
     frag(nx, 0, 0);
@@ -2625,27 +1753,17 @@ bool wino4_gemm_uses_pp(const Wino4Gemm& p) {
 }
 
 void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {
-  static const int shape = getenv("CRNN_WINO4_SHAPE") ? atoi(getenv("CRNN_WINO4_SHAPE")) : 4;
-  const int nwn = (shape == 2 || p.N % 128) ? 2 : 4;
-  const int units = p.ncomp * (p.ntile_pad / 128) * (p.N / (32 * nwn));
-  const int slots = nwn == 2 ? 512 : 256;
-  const int g = units < slots ? 8 * ((units + 7) / 8) : slots;
-  static const int lw = getenv("CRNN_WINO4_LW") ? atoi(getenv("CRNN_WINO4_LW")) : 1;
-  if (p.h3) {   // operands in the f16x3 format (N % 128 == 0 checked by the caller)
-    const int u3 = p.ncomp * (p.ntile_pad / 128) * (p.N / 128);
-    static const int h3lw = getenv("CRNN_H3_LW") ? atoi(getenv("CRNN_H3_LW")) : 256;   // loader waves from this K (0 = never)
-    if (wino4_gemm_uses_pp(p)) {
-      const int u2 = p.ncomp * (p.ntile_pad / 256) * (p.N / 128);
-      hipLaunchKernelGGL(wino4_gemm_h3_pp_kernel, dim3(u2 < persistent_blocks() ? 8 * ((u2 + 7) / 8) : persistent_blocks()), dim3(768), 0, s, p);
-    } else if (h3lw > 0 && p.Cin >= h3lw)
-      hipLaunchKernelGGL((wino4_gemm_h3_lw_kernel<4>), dim3(u3 < persistent_blocks() ? 8 * ((u3 + 7) / 8) : persistent_blocks()), dim3(768), 0, s, p);
-    else
-      hipLaunchKernelGGL(wino4_gemm_h3_kernel, dim3(u3 < persistent_blocks() ? 8 * ((u3 + 7) / 8) : persistent_blocks()), dim3(512), 0, s, p);
-    return;
+  // units of 128 tiles x 128 channels (N % 128 == 0 checked by the caller), one persistent block per CU slot
+  const int u = p.ncomp * (p.ntile_pad / 128) * (p.N / 128);
+  const int g = u < persistent_blocks() ? 8 * ((u + 7) / 8) : persistent_blocks();
+  if (!p.h3) {   // f32 MFMA (CRNN_F16X3=0)
+    hipLaunchKernelGGL(wino4_gemm_lw_kernel, dim3(g), dim3(576), 0, s, p);
+  } else if (wino4_gemm_uses_pp(p)) {
+    const int u2 = p.ncomp * (p.ntile_pad / 256) * (p.N / 128);
+    hipLaunchKernelGGL(wino4_gemm_h3_pp_kernel, dim3(u2 < persistent_blocks() ? 8 * ((u2 + 7) / 8) : persistent_blocks()), dim3(768), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((wino4_gemm_h3_lw_kernel<4>), dim3(g), dim3(768), 0, s, p);
   }
-  if (nwn == 2) hipLaunchKernelGGL((wino4_gemm_kernel<2>), dim3(g), dim3(256), 0, s, p);
-  else if (lw) hipLaunchKernelGGL(wino4_gemm_lw_kernel, dim3(g), dim3(576), 0, s, p);
-  else hipLaunchKernelGGL((wino4_gemm_kernel<4>), dim3(g), dim3(512), 0, s, p);
 }
 void launch_wino4_in(const float* x, float* V, int B, int H, int W, int C, hipStream_t s, float* vs) {
   const long total = wino4_tiles(B, H, W) * (C / 4);
@@ -3292,7 +2410,8 @@ __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restric
 
 void launch_lstm_rec_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T, float unscale,
                         hipStream_t s, const unsigned* gate) {
-  static const bool res = !(getenv("CRNN_REC_RES") && atoi(getenv("CRNN_REC_RES")) == 0);
+  const char* re = getenv("CRNN_REC_RES");       // read per launch (a test switches it inside one process)
+  const bool res = !(re && atoi(re) == 0);
   if (res)
     hipLaunchKernelGGL(lstm_rec_h3_kernel<true>, dim3((B + LB - 1) / LB, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen,
                        B, T, unscale, gate);
@@ -3357,162 +2476,10 @@ float pack_whh_h3(const float* whh_fwd, const float* whh_rev, uint16_t* packed /
 constexpr unsigned SPLIT_MAX_SPINS = 1u << 16;
 typedef __attribute__((address_space(1))) unsigned gu32_t;
 
-__global__ __launch_bounds__(256) void lstm_rec_split_kernel(const float* __restrict__ xp,
-                                                             const float* __restrict__ whhp, float* rec,
-                                                             const int32_t* __restrict__ tlen, int B, int T,
-                                                             unsigned* tmo) {
-  __shared__ __attribute__((aligned(16))) float hs[2 * LB * HS];
-  __shared__ int s_fail;
-  const int dir = blockIdx.y, grp = blockIdx.x >> 2, part = blockIdx.x & 3, b0 = grp * LB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
-  const int b = b0 + bl;
-  const int Ti = (b < B) ? (tlen ? tlen[b] : T) : 0;
-  int Tmax = 0;
-  for (int j = 0; j < LB; j++) {
-    const int bb = b0 + j;
-    const int tj = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
-    Tmax = tj > Tmax ? tj : Tmax;
-  }
-  for (int i = tid; i < 2 * LB * HS; i += 256) hs[i] = 0.f;
-  if (tid == 0) s_fail = 0;
-  // exchange loads: 3 other parts x 16 lines x 16 chunks of 4 units = 768 float4, 3 per thread
-  int xl_line[3], xl_unit[3], xl_T[3];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const int e = i * 256 + tid;            // 0..767
-    const int op = e >> 8;                  // which of the 3 other parts
-    const int p2 = op + (op >= part ? 1 : 0);
-    xl_line[i] = (e >> 4) & 15;
-    xl_unit[i] = p2 * 64 + (e & 15) * 4;
-    const int bb = b0 + xl_line[i];
-    xl_T[i] = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
-  }
-  const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, 0x7FFFFFFF, 0x00020000);
-  float c[4], h[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) { c[r] = 0.f; h[r] = 0.f; }
-  // the wave's weights: gate g, its 16 units, all 16 k-groups -- 64 float4 per lane, resident
-  f32x4 w[4][16];
-  {
-    const f32x4* wp = (const f32x4*)whhp + ((size_t)(dir * 4 + part) * 16 * 16) * 64 + lane;
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-      for (int kg = 0; kg < 16; kg++) w[g][kg] = wp[(size_t)((g * 4 + wave) * 16 + kg) * 64];
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int s = 0; s < Tmax; s++) {
-    const bool active = s < Ti;
-    const int t = active ? (dir ? (Ti - 1 - s) : s) : 0;
-    const size_t rowi = (size_t)(b < B ? b : 0) * T + t;
-    const float* xrow = xp + rowi * 2048 + dir * 1024 + part * 64 + wave * 16 + q * 4;
-    f32x4 xg[4], acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      xg[g] = active ? *(const f32x4*)(xrow + g * 256) : z;
-      acc[g] = z;
-    }
-    const float* hrow = hs + cur * LB * HS + bl * HS + 4 * q;
-#pragma unroll
-    for (int kg = 0; kg < 16; kg++) {
-      const f32x4 hv = *(const f32x4*)(hrow + kg * 16);
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][kg][j], hv[j], acc[g], 0, 0, 0);
-    }
-    f32x4 hv4;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if (active) {
-        const float ig = sigmoidf_(acc[0][r] + xg[0][r]);
-        const float fg = sigmoidf_(acc[1][r] + xg[1][r]);
-        const float gg = tanhf_(acc[2][r] + xg[2][r]);
-        const float og = sigmoidf_(acc[3][r] + xg[3][r]);
-        c[r] = fg * c[r] + ig * gg;
-        h[r] = og * tanhf_(c[r]);
-      }
-      hv4[r] = h[r];
-    }
-    const int myu = part * 64 + wave * 16 + q * 4;
-    *(f32x4*)(hs + (cur ^ 1) * LB * HS + bl * HS + myu) = hv4;
-    if (active)   // write-through store: the output row AND the hand-off to the other three workgroups
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv4), rec_rsrc,
-                                             (unsigned)((rowi * 512 + dir * 256 + myu) * 4), 0, 16);
-    // The other parts' h of this step.  The launcher filled the whole output tensor with the bit pattern
-    // 0xFFFFFFFF (no h value has it) and every row is written exactly once, so the data is its own arrival flag:
-    // each thread polls its three 16-byte chunks with sc1 loads (L1 bypassed) until all four words of each have
-    // changed -- no drain of the stores, no counter round trip, and no assumption that the 16 bytes arrive
-    // together.  Lines that have ended keep their old value.  Spins are bounded; see the time-out word.
-    {
-      i32x4 v[3];
-      bool act[3], pend[3];
-      unsigned ro[3];
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const int Tl = xl_T[i], ln = xl_line[i];
-        act[i] = s < Tl;
-        const int tl = dir ? (Tl - 1 - s) : s;
-        ro[i] = (unsigned)((((size_t)(b0 + ln) * T + tl) * 512 + dir * 256 + xl_unit[i]) * 4);
-        pend[i] = act[i];
-      }
-      unsigned spins = 0;
-      bool fail = false;
-      while (pend[0] || pend[1] || pend[2]) {
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-          if (pend[i]) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, ro[i], 0, 16);
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-          if (pend[i]) pend[i] = v[i][0] == -1 || v[i][1] == -1 || v[i][2] == -1 || v[i][3] == -1;
-        if (++spins > SPLIT_MAX_SPINS) { fail = true; break; }
-        if ((spins & 255u) == 0 &&
-            __hip_atomic_load((gu32_t*)tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = true; break; }
-      }
-      if (fail) {
-        __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_fail = 1;
-      }
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        float* dst = hs + (cur ^ 1) * LB * HS + xl_line[i] * HS + xl_unit[i];
-        if (act[i]) *(f32x4*)dst = __builtin_bit_cast(f32x4, v[i]);
-        else *(f32x4*)dst = *(const f32x4*)(hs + cur * LB * HS + xl_line[i] * HS + xl_unit[i]);
-      }
-    }
-    __syncthreads();
-    if (s_fail) return;     // uniform: everybody leaves; the host repeats the batch with lstm_rec_kernel
-    __syncthreads();
-    cur ^= 1;
-  }
-  // padding rows (t >= T_i) of this workgroup's lines, direction and 64 units: zero instead of the fill pattern
-  for (int ln = 0; ln < LB; ln++) {
-    const int bb = b0 + ln;
-    if (bb >= B) break;
-    const int Tl = tlen ? tlen[bb] : T;
-    for (int r = Tl * 16 + tid; r < T * 16; r += 256)
-      *(f32x4*)(rec + ((size_t)bb * T + (r >> 4)) * 512 + dir * 256 + part * 64 + (r & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-}
-
-// tmo: one device word, zeroed by the caller, set to 1 by the kernel when a hand-off timed out
-void launch_lstm_rec_split(const float* xp, const float* whh_packed, float* rec, const int32_t* tlen, int B,
-                           int T, unsigned* tmo, hipStream_t s) {
-  const int groups = (B + LB - 1) / LB;
-  // the output rows double as arrival flags: fill them with a bit pattern no h value has (every row a step can
-  // poll must carry it, and with ragged lengths those rows are scattered, so the whole tensor is filled: 37 MB at
-  // 256 lines, ~10 us)
-  (void)hipMemsetAsync(rec, 0xFF, (size_t)B * T * 512 * sizeof(float), s);
-  hipLaunchKernelGGL(lstm_rec_split_kernel, dim3(groups * 4, 2), dim3(256), 0, s, xp, whh_packed, rec, tlen, B, T,
-                     tmo);
-}
 
 // ---------------------------------------------------------------------------
-// The hidden-split recurrence on the fp16 MFMA in the f16x3 form: lstm_rec_split_kernel's work split, exchange protocol
-// and time-out handling, lstm_rec_h3_kernel's arithmetic.  Workgroup `part` owns hidden units [64 part, 64 part + 64) of
+// The hidden-split recurrence (the work split, exchange protocol and time-out handling described above; its first, f32-MFMA
+// form is gone) on the fp16 MFMA in the f16x3 form, i.e. with lstm_rec_h3_kernel's arithmetic.  Workgroup `part` owns hidden units [64 part, 64 part + 64) of
 // all four gates, wave w the 16 units [.. + 16 w, ..); the wave's W_hh slice -- 4 gate tiles x 8 k-steps x (hi, lo)
 // fragments in pack_whh_h3's order, 64 KB, the same 256 registers as the fp32 slice -- stays resident, h lives in LDS
 // as split pairs (scale 2^14, lstm_rec_h3_kernel's layout), and a step is 96 v_mfma_f32_16x16x32_f16 per wave (0.7 us)
@@ -3622,7 +2589,7 @@ __global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __r
     if (active)   // write-through store: the output row AND the hand-off to the other three workgroups
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv4), rec_rsrc,
                                              (unsigned)((rowi * 512 + dir * 256 + myu) * 4), 0, 16);
-    // the other parts' h of this step: lstm_rec_split_kernel's protocol (the fill pattern is the arrival flag)
+    // the other parts' h of this step: the protocol described above (the fill pattern is the arrival flag)
     {
       i32x4 v[3];
       bool act[3], pend[3];
@@ -3681,7 +2648,10 @@ __global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __r
 void launch_lstm_rec_split_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T,
                               float unscale, unsigned* tmo, hipStream_t s) {
   const int groups = (B + LB - 1) / LB;
-  (void)hipMemsetAsync(rec, 0xFF, (size_t)B * T * 512 * sizeof(float), s);   // the arrival flags (see launch_lstm_rec_split)
+  // tmo: one device word, zeroed by the caller, set to 1 by the kernel when a hand-off timed out.  The output rows double
+  // as arrival flags: fill them with a bit pattern no h value has (every row a step can poll must carry it, and with
+  // ragged lengths those rows are scattered, so the whole tensor is filled: 37 MB at 256 lines, ~10 us)
+  (void)hipMemsetAsync(rec, 0xFF, (size_t)B * T * 512 * sizeof(float), s);
   hipLaunchKernelGGL(lstm_rec_split_h3_kernel, dim3(groups * 4, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen, B,
                      T, unscale, tmo);
 }
@@ -3706,31 +2676,6 @@ void pack_whh(const float* whh_fwd, const float* whh_rev, float* packed) {
             for (int j = 0; j < 4; j++) dst[j] = w[(size_t)row * 256 + k + j];
           }
   }
-}
-
-// ---------------------------------------------------------------------------
-// argmax over classes, one wave per row; ties -> lowest index (torch CPU max)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits,
-                                                     int32_t* __restrict__ idx, int M, int nclass,
-                                                     int ld) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const float* p = logits + (long)row * ld;
-  float bv = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int k = lane; k < nclass; k += 64) {
-    const float v = p[k];
-    if (v > bv || bi == 0x7fffffff) { bv = v; bi = k; }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ov = __shfl_xor(bv, off);
-    const int oi = __shfl_xor(bi, off);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-  }
-  if (lane == 0) idx[row] = bi;
 }
 
 __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* __restrict__ pmax,
@@ -3858,9 +2803,6 @@ uint16_t f32_to_f16_host(float f) {
   return u;
 }
 
-void launch_argmax(const float* logits, int32_t* idx, int M, int nclass, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, idx, M, nclass, ld);
-}
 
 // ---------------------------------------------------------------------------
 // greedy CTC collapse, one wave per line: lane i looks at timestep base + i and its predecessor, the kept labels are

@@ -209,7 +209,7 @@ void launch_conv_gemm_bf16(const ConvGemm& p, int out_mode, hipStream_t s) {
 // the rate at which a CU can pull operands through L1 (about 45 GB/s per CU, 11 TB/s over the chip, measured on the
 // Winograd GEMMs), so the unit is as large as the registers allow: 256 x 256 per block, 8 waves as 2 (M) x 4 (N),
 // wave tile 128 x 64 = 8 accumulators of v_mfma_f32_32x32x16 (128 registers).  K in steps of 64 (128 bytes per row,
-// the XOR-swizzled row-pair layout of wino4_gemm_kernel), two 64 KB stages; every wave issues 8 of the 64 loads of a
+// the XOR-swizzled row-pair layout of wino4_gemm_lw_kernel), two 64 KB stages; every wave issues 8 of the 64 loads of a
 // step.  The barrier of a step sits after its last fragment read and before its last 8 MFMAs: behind it the stage is
 // refilled with step + 2, ahead of it every wave has waited for its loads of step + 1.  Persistent, units with the
 // column block fastest (the 22 column blocks of the classifier share their A rows in one XCD's L2).

@@ -270,18 +270,18 @@ def test_pages_from_two_threads_use_their_own_lanes(golden, zh3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rec_h3", ["0", "1"])
-def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh, rec_h3):
-    """Small batches use the four-workgroups-per-group recurrence (lstm_rec_split_kernel / lstm_rec_split_h3_kernel) in
-    the synchronous host paths; it must reproduce the one-workgroup kernel of the same arithmetic bit for bit: same logits
-    for n = 1, 17, 48 and 200 lines of different widths (lines ending at different steps exercise the keep-old-h path of
-    the exchange).  rec_h3 = "0": both on the f32 MFMA; "1": both in the f16x3 form (the two forms are equally accurate
-    but not bit-identical to each other)."""
+@pytest.mark.parametrize("rec_res", ["1", "0"])
+def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh, rec_res):
+    """Small batches use the four-workgroups-per-group recurrence (lstm_rec_split_h3_kernel) in the synchronous host paths;
+    it must reproduce the one-workgroup kernel of the same arithmetic (lstm_rec_h3_kernel) bit for bit: same logits for
+    n = 1, 17, 48 and 200 lines of different widths (lines ending at different steps exercise the keep-old-h path of the
+    exchange).  rec_res: the one-workgroup kernel with a quarter of W_hh resident ("1", the default) and streaming all of
+    it ("0"; CRNN_REC_RES is read at every launch)."""
     from ocr_amd.crnn.network_hip import CRNN
     G, M = golden
     old = os.environ.get("CRNN_LSTM_SPLIT")
-    old_h3 = os.environ.get("CRNN_REC_H3")
-    os.environ["CRNN_REC_H3"] = rec_h3
+    old_res = os.environ.get("CRNN_REC_RES")
+    os.environ["CRNN_REC_RES"] = rec_res
     try:
         os.environ["CRNN_LSTM_SPLIT"] = "0"
         ref = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1)
@@ -294,10 +294,6 @@ def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh, rec_h3):
             os.environ.pop("CRNN_LSTM_SPLIT", None)
         else:
             os.environ["CRNN_LSTM_SPLIT"] = old
-        if old_h3 is None:
-            os.environ.pop("CRNN_REC_H3", None)
-        else:
-            os.environ["CRNN_REC_H3"] = old_h3
     rs = np.random.RandomState(5)
     inv = [G[k] for k in sorted(G.files) if k.startswith("inv/") and k.endswith("/bgr")]
     pool = inv + [rs.randint(0, 256, size=(32, int(w))).astype(np.uint8) for w in rs.randint(8, 700, size=40)]
@@ -314,6 +310,10 @@ def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh, rec_h3):
     lines = [rs.randint(0, 256, size=(32, int(w))).astype(np.uint8) for w in rs.randint(40, 90, size=512)]
     a = ref._run(lines, 0, want_raw=True)     # 0 = PAD_PER_LINE: every line decoded as if alone
     b = spl._run(lines, 0, want_raw=True)
+    if old_res is None:
+        os.environ.pop("CRNN_REC_RES", None)
+    else:
+        os.environ["CRNN_REC_RES"] = old_res
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
 
 
