@@ -243,9 +243,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=0,
                     help="independent stream/workspace lanes per GPU (2 since round 3: with the hidden-split recurrence in the "
-                         "pipelined path a batch alone takes 2.9 ms instead of 3.9, and two in flight fill the chip)")
+                         "pipelined path a batch alone takes 2.9 ms instead of 3.9, and two in flight fill the chip; the bf16 "
+                         "path keeps the one-workgroup recurrence and four lanes); 0 = that default")
     ap.add_argument("--lines", type=int, default=0,
                     help="BASELINE configs[3]: a fixed job of this many synthetic 32x280 lines (1000000 in the config), "
                          "generated on-device from --seed and sharded over the ranks; 0 = the default per-step mode")
@@ -257,6 +258,8 @@ def main():
                     help="one batch at a time (for rocprofv3 --kernel-trace --stats: per-kernel durations that are "
                          "not stretched by the other lanes, with the tile shapes the pipelined run uses)")
     args = ap.parse_args()
+    if args.lanes <= 0:
+        args.lanes = 2 if args.precision == "fp32" else 4
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # called without a launcher: be the launcher.  Nothing in this process has touched HIP yet (torch is not even

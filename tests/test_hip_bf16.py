@@ -67,7 +67,8 @@ def test_bf16_character_agreement_report(golden, bf16_zh, bf16_en):
     lines = list(G["syn280/noise/gray"]) + list(G["syn280/text/gray"])
     a_syn = agreement(bf16_zh.predict_lines(lines), M["syn280_noise"] + M["syn280_text"])
     print("\nbf16 character agreement: invoice zh %.3f, invoice en %.3f, synthetic-280 zh %.3f" % (a_zh, a_en, a_syn))
-    assert a_zh > 0.5 and a_en > 0.5 and a_syn > 0.5
+    # measured on the round-3 build: 0.800 / 0.834 / 0.864 (deterministic for a given build); the floor leaves a small margin
+    assert a_zh >= 0.75 and a_en >= 0.78 and a_syn >= 0.80
     # deterministic
     assert bf16_zh.predict_lines(crops) == bf16_zh.predict_lines(crops)
 
