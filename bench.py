@@ -507,10 +507,15 @@ def main():
             fams.append(family("wino4_gemm_lw_kernel", wino4_names,
                                "Winograd component GEMMs of a layer as one persistent launch of 128x128 units on the f32 MFMA", 1,
                                PEAK_F32_MFMA_TFLOPS))
-    if fused4_names:
-        fams.append(family("wino4_fused_h3_kernel", fused4_names,
-                           "the 36 Winograd component GEMMs of a layer AND its output transform (+ bias, activation, pool1) in one "
-                           "persistent launch of 64x64 units, no product tensor; fp16 MFMA, f16x3 operands", 3, PEAK_BF16_MFMA_TFLOPS))
+    # (one family per kernel SYMBOL: conv1 runs the POOL = 1 instantiation of the fused kernel, conv2 the POOL = 0 one)
+    for inst, names in (("wino4_fused_h3_kernel<1>", [n for n in fused4_names if n.startswith("conv1")]),
+                        ("wino4_fused_h3_kernel<0>", [n for n in fused4_names if not n.startswith("conv1")])):
+        if names:
+            fams.append(family(inst, names,
+                               "the 36 Winograd component GEMMs of a layer AND its output transform (+ bias, activation%s) in one "
+                               "persistent launch of 64x64 units, no product tensor; fp16 MFMA, f16x3 operands; bound by operand "
+                               "delivery from L2 (its 64 x 64 unit needs 32 KB of operands per 384 MFMA cycles)"
+                               % (", pool1" if inst.endswith("<1>") else ""), 3, PEAK_BF16_MFMA_TFLOPS))
     if lin_names:
         h3l = [n for n in lin_names if h3 and n != "classifier"]
         if h3l:
