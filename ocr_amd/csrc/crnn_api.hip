@@ -79,6 +79,7 @@ struct Lane {
   int page_h = 0, page_w = 0, page_ch = 0;
   int pblocks = 256;           // blocks of the persistent GEMM launches of the next network run (set_persistent_blocks)
   bool want_p0 = false;        // crnn_debug_stage(.., 0): keep the pooled conv0 output (no conv0 / input transform fusion)
+  int want_stage = -1;         // crnn_debug_stage(.., 3 / 4 / 5): keep pool2's / conv4's / pool3's output (no chained transform kernel there)
   float* st[11] = {};          // where the stages of the last run live (crnn_debug_stage)
   size_t st_floats[11] = {};
 };
@@ -409,7 +410,8 @@ struct Plan {
   float* anorm;   // [n*T] its row norms
   float* pmax;   // [n*T][n-tiles of the classifier]
   float *wv, *wm; // Winograd V[16][tiles][Cin] and Mo[16][tiles][Cout] (largest enabled layer)
-  float* vs;      // f16x3: per-tile unscale factors of the current layer's V (largest tile count)
+  float *vs, *vs2; // f16x3: per-tile unscale factors of the current layer's V (largest tile count); vs2: of the next
+                   // layer's V while a chained transform kernel (wino4_out_in_h3_kernel) still reads this layer's
   float *a3, *rs; // f16x3 copy of a plain GEMM's A operand [n*T][512] and its per-128-row unscale factors
   int32_t* pidx;
   size_t bytes;
@@ -474,6 +476,7 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
       tmax = std::max(tmax, (size_t)wino4_pad((long)n * ((g.T + 3) / 4)));
     }
     p.vs = take(tmax);
+    p.vs2 = take(tmax);
     p.a3 = take(h->h3 && h->cfg.lstm ? n * g.T * 512 : 0);
     p.rs = take(h->h3 && h->cfg.lstm ? (n * g.T + 127) / 128 : 0);
   }
@@ -537,9 +540,17 @@ static bool conv1_on_wino4_h3(const crnn_handle* h, int n) {
 
 // pool_out: where a following MaxPool 2x2/2 would write; the fused Winograd kernel can apply it
 // itself (one tile == one pool window).  Returns true when it did, so the caller skips the pool.
-bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
-          int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr, float* pool_out = nullptr,
-          float* pool21_out = nullptr, float* vs = nullptr, bool v_ready = false) {
+// chain_src >= 0 (with vs_next): instead of the output transform, wino4_out_in_h3_kernel may write the NEXT layer's V and
+// scales (0: this layer's map feeds it directly, 1: through pool2, 2: through pool3 into conv6's F(4,2)); returns 2 then,
+// and the caller passes v_ready there.
+static bool conv_on_wino4_h3(const crnn_handle* h, int layer, int n, int Cin) {
+  return h->cfg.precision != CRNN_BF16 && h->h3 && layer >= 1 && layer <= 5 && ((h->wino4_mask >> layer) & 1u) &&
+         use_wino4(h, n) && h->d_wino4h[layer] && NM[layer] % 128 == 0 && (Cin & (Cin - 1)) == 0 && Cin >= 64 && Cin <= 512;
+}
+int conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
+         int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr, float* pool_out = nullptr,
+         float* pool21_out = nullptr, float* vs = nullptr, bool v_ready = false, int chain_src = -1,
+         float* vs_next = nullptr) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   const bool b16 = h->cfg.precision == CRNN_BF16;
   // (with f16x3 weights only the split form of U exists: a shape that form does not take falls through to the direct conv)
@@ -576,7 +587,7 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
       launch_wino4_fused(f, s);
       const double px = pool_out ? (double)n * (Hin / 2) * (Win / 2) : (double)n * Hin * Win;
       kmark(h, wf4[layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * (36.0 * ((double)tiles * Cin + (double)Co * Cin) + px * Co));
-      return pool_out != nullptr;
+      return pool_out != nullptr ? 1 : 0;
     }
     Wino4Gemm w{};
     w.V = wino_v; w.U = h3 ? (const float*)h->d_wino4h[layer] : h->d_wino4[layer]; w.M = wino_m; w.ntile_pad = (int)tp;
@@ -584,6 +595,25 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     launch_wino4_gemm(w, s);
     static const char* wn4pp[7] = {"", "conv1_f4pp", "conv2_f4pp", "conv3_f4pp", "conv4_f4pp", "conv5_f4pp", ""};
     kmark(h, wino4_gemm_uses_pp(w) ? wn4pp[layer] : wn4[1][layer], 2.0 * 36 * tiles * Co * Cin, 4.0 * 36 * ((double)tiles * Cin + (double)Co * Cin + (double)tiles * Co));
+    // CRNN_WINO4_CHAIN (bit mask of layers, default conv3 and conv4; read per call): this layer's output transform and
+    // the next layer's input transform as one kernel -- the activation between them is never written
+    // (as for the pooled output transform: one thread walks a row of tiles, too few of them below ~128 lines)
+    const bool next_ok = chain_src == 2 ? (h->wino6 && h->d_wino4h[6] != nullptr && Co == 512)   // (conv()'s own test for conv6)
+                                        : conv_on_wino4_h3(h, layer + 1, n, Co);
+    if (chain_src >= 0 && h3 && vs_next && !pool_out && n >= 128 && (chain_src >= 1) == (pool21_out != nullptr) &&
+        next_ok && wino4_out_in_ok(n, Hin, Win, Co, chain_src)) {
+      const char* e = getenv("CRNN_WINO4_CHAIN");
+      const unsigned mask = e ? (unsigned)strtoul(e, nullptr, 0) : 0x38u;
+      if ((mask >> layer) & 1u) {
+        launch_wino4_out_in(wino_m, h->d_conv_b[layer], vs, h->wino4_us[layer], wvalid, wino_v, vs_next, n, Hin, Win, Co,
+                            h->cfg.leaky_relu ? 2 : 1, chain_src, s);
+        const int Wn = chain_src ? Win + 1 : Win;
+        const double vnext = chain_src == 2 ? 5.0 * (double)n * ((Wn - 1 + 3) / 4) * 2 * Co : 36.0 * (double)wino4_tiles(n, 4, Wn) * Co;
+        kmark(h, layer == 3 ? "conv3_wout4_pool2_win4" : (layer == 4 ? "conv4_wout4_win4" : "conv5_wout4_pool3_win4"), 0,
+              4.0 * (36.0 * (double)tiles * Co + vnext));
+        return 2;
+      }
+    }
     float* dst = pool_out ? pool_out : (pool21_out ? pool21_out : (float*)C);
     launch_wino4_out(wino_m, h->d_conv_b[layer], dst, wvalid, n, Hin, Win, Co, h->cfg.leaky_relu ? 2 : 1,
                      pool_out ? 1 : (pool21_out ? 2 : 0), s, h3 ? vs : nullptr, h->wino4_us[layer]);
@@ -591,7 +621,7 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
                                   : (pool21_out ? (double)n * (Hin / 2) * (Win + 1) : (double)n * Hin * Win);
     kmark(h, pool21_out ? (layer == 3 ? "conv3_wout4_pool2" : "conv5_wout4_pool3") : wn4[2][layer], 0,
           4.0 * (36.0 * tiles * Co + outpx * Co));
-    return pool_out != nullptr || pool21_out != nullptr;
+    return pool_out != nullptr || pool21_out != nullptr ? 1 : 0;
   }
   const bool h3_ok6 = h->h3 && layer == 6 && h->d_wino4h[6] && vs && Cin == 512;
   if (!b16 && layer == 6 && h->wino6 && wino_v && wino_m && use_wino4(h, n) && (h3_ok6 || h->d_wino4[6])) {
@@ -600,8 +630,10 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     const long tiles = (long)n * ((Wout + 3) / 4), tp = wino4_pad(tiles);
     hipStream_t s = tl_cur->stream;
     const bool h3 = h3_ok6;
-    launch_wino42_in((const float*)A, wino_v, n, Win, Cin, s, h3 ? vs : nullptr);
-    kmark(h, "conv6_win4", 0, 4.0 * ((double)n * 2 * Win * Cin + 5.0 * tiles * 2 * Cin));
+    if (!v_ready) {   // (wino4_out_in_h3_kernel<2> may have written V and vs from conv5's products)
+      launch_wino42_in((const float*)A, wino_v, n, Win, Cin, s, h3 ? vs : nullptr);
+      kmark(h, "conv6_win4", 0, 4.0 * ((double)n * 2 * Win * Cin + 5.0 * tiles * 2 * Cin));
+    }
     Wino4Gemm w{};
     w.V = wino_v; w.U = h3 ? (const float*)h->d_wino4h[6] : h->d_wino4[6]; w.M = wino_m; w.ntile_pad = (int)tp; w.N = Co;
     w.Cin = 2 * Cin; w.ncomp = 5; w.h3 = h3;
@@ -610,7 +642,7 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
     launch_wino42_out(wino_m, h->d_conv_b[6], (float*)C, n, Wout, Co, h->cfg.leaky_relu ? 2 : 1, s, h3 ? vs : nullptr,
                       h->wino4_us[6]);
     kmark(h, "conv6_wout4", 0, 4.0 * (5.0 * tiles * Co + (double)n * Wout * Co));
-    return false;
+    return 0;
   }
   ConvGemm p{};
   p.A = (const float*)A; p.Wt = b16 ? (const float*)h->db_conv_w[layer] : h->d_conv_w[layer];
@@ -624,7 +656,7 @@ bool conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wval
   const double es = b16 ? 2.0 : 4.0;
   kmark(h, names[layer], 2.0 * p.M * p.N * p.K,
         es * ((double)n * Hin * Win * Cin + (double)p.N * p.K + (double)p.M * p.N));
-  return false;
+  return 0;
 }
 
 // Runs the network on the normalised input already in plan.x.  widths: host
@@ -673,18 +705,30 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     kmark(h, "pool1", 0, es * (dn * 16 * g.W1 * 128 + dn * 8 * g.W2 * 128));
   }
   conv(h, 2, p.p1, p.c2, m_w2, n, 8, g.W2, 128, 8, g.W2, p.wv, p.wm, nullptr, nullptr, p.vs);
-  if (!conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2, p.wv, p.wm, nullptr, p.p2, p.vs)) {
+  // conv3 -> pool2 -> conv4 and conv4 -> conv5: output transform + next input transform as one kernel where conv() can
+  // (the scales of the two layers alternate between vs and vs2; a debug request for the stage in between gets it written)
+  float *vs_a = p.vs, *vs_b = p.vs2;
+  const int st_want = tl_cur->want_stage;
+  int r3 = conv(h, 3, p.c2, p.c3, m_w2, n, 8, g.W2, 256, 8, g.W2, p.wv, p.wm, nullptr, p.p2, vs_a, false,
+                st_want == 3 ? -1 : 1, vs_b);
+  if (r3 == 2) std::swap(vs_a, vs_b);
+  else if (!r3) {
     if (b16) launch_pool_2x2s21p01_bf16(p.c3, p.p2, n, 8, g.W2, 256, s);
     else launch_pool_2x2s21p01(p.c3, p.p2, n, 8, g.W2, 256, s);
     kmark(h, "pool2", 0, es * (dn * 8 * g.W2 * 256 + dn * 4 * g.W3 * 256));
   }
-  conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3, p.wv, p.wm, nullptr, nullptr, p.vs);
-  if (!conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3, p.wv, p.wm, nullptr, p.p3, p.vs)) {
+  const int r4 = conv(h, 4, p.p2, p.c4, m_w3, n, 4, g.W3, 256, 4, g.W3, p.wv, p.wm, nullptr, nullptr, vs_a, r3 == 2,
+                      st_want == 4 ? -1 : 0, vs_b);
+  if (r4 == 2) std::swap(vs_a, vs_b);
+  const int r5 = conv(h, 5, p.c4, p.c5, m_w3, n, 4, g.W3, 512, 4, g.W3, p.wv, p.wm, nullptr, p.p3, vs_a, r4 == 2,
+                      st_want == 5 ? -1 : 2, vs_b);
+  if (r5 == 2) std::swap(vs_a, vs_b);
+  else if (!r5) {
     if (b16) launch_pool_2x2s21p01_bf16(p.c5, p.p3, n, 4, g.W3, 512, s);
     else launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
     kmark(h, "pool3", 0, es * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
   }
-  conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T, p.wv, p.wm, nullptr, nullptr, p.vs);
+  conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T, p.wv, p.wm, nullptr, nullptr, vs_a, r5 == 2);
   HIPCHK(h, hipEventRecord(tl_cur->ev[2], s));
   const int M = n * g.T;
   const double recflop = 2.0 * M * 2 * 1024 * 256;
@@ -1607,8 +1651,10 @@ int crnn_debug_stage(crnn_handle* h, const float* x, int32_t n, int32_t w, const
   HIPCHK(h, hipMemcpyAsync(p.x, x, sizeof(float) * (size_t)n * 32 * w, hipMemcpyHostToDevice, tl_cur->stream));
   HIPCHK(h, hipEventRecord(tl_cur->ev[0], tl_cur->stream));
   tl_cur->want_p0 = stage == 0;
+  tl_cur->want_stage = stage;
   rc = run_network(h, g, p, widths, d_lab, d_len, true);
   tl_cur->want_p0 = false;
+  tl_cur->want_stage = -1;
   if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(tl_cur->stream));
   if ((size_t)out_floats < tl_cur->st_floats[stage]) return fail(h, CRNN_ERR_ARG, "out_host too small for this stage");

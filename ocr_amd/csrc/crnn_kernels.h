@@ -210,6 +210,11 @@ void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s);
 // vs / us: unscale factors of f16x3 products (per tile, per layer) or nullptr / 1
 void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t* wvalid, int B, int H, int W,
                       int Cout, int act, int pool, hipStream_t s, const float* vs = nullptr, float us = 1.f);
+// layer L's output transform + layer L + 1's input transform (f16x3 form) in one kernel: M of layer L -> V and vs_out of
+// layer L + 1.  src 0: H = 4, layer L + 1 reads the map as it is; src 1: H = 8, MaxPool (2,2)/(2,1)/pad (0,1) in between
+bool wino4_out_in_ok(int B, int H, int W, int C, int src);
+void launch_wino4_out_in(const float* M, const float* bias, const float* vs_in, float us, const int32_t* wvalid, float* V,
+                         float* vs_out, int B, int H, int W, int C, int act, int src, hipStream_t s);
 // fp32 rows [M][K] (K = 256 or 512; false for any other K) -> f16x3 rows + one unscale factor per block of 128 rows
 bool launch_rows_to_f16x3(const float* A, float* out, float* rs, int M, int K, hipStream_t s);
 // host: rows of K floats -> the f16x3 format with ONE scale for the whole tensor; returns 1 / scale

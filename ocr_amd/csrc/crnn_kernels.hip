@@ -471,6 +471,306 @@ __global__ __launch_bounds__(256) void wino4_out_pool21_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------
+// Output transform of layer L AND input transform of layer L + 1 in one kernel (f16x3 path: conv3 -> pool2 -> conv4 and
+// conv4 -> conv5): the activation between the two layers, written and read back by the two-kernel form, only exists
+// in registers.  The next layer's tile scale is a maximum over ALL channels of the tile, so a workgroup is the C / 4
+// threads of all channels (one or two waves); it owns a segment of one line's row of tiles and walks along x.  Step tx
+// computes the 4 x 4 tile tx of the next layer's input map -- SRC 0: A^T m A of tile tx (the map is 4 rows high);
+// SRC 1: of the two tiles above each other, max-pooled (2,2)/(2,1)/pad (0,1) as wino4_out_pool21_kernel does (8 rows ->
+// 4, W -> W + 1 columns) -- after which the 6 x 6 patch of the next layer's tile tx - 1 is complete: column 3 of tile
+// tx - 2, tile tx - 1, column 0 of tile tx, rows -1 and 4 the zero padding.  It goes through the arithmetic of
+// wino4_in_h3_kernel: the same operations on the same values as the kernels this one replaces, so V and the scales are
+// bit-identical to theirs (tests/test_hip_chain.py).  A segment computes the tile before and the tile after its own for
+// their edge columns (two segments: 11 % more M reads).  Few threads, but each has 36 independent 16-byte loads in
+// flight per step, and with one wave per SIMD (400-480 registers) the chip still has ~35 MB on the way.
+// SRC 2 is conv5 -> pool3 -> conv6: the map is 4 rows high, the pool leaves 2, and the next layer is the 1-D F(4,2)
+// of wino42_in_h3_kernel (tile tx - 1 = pooled columns 4 (tx - 1) .. 4 tx of both rows; scale = the exact maximum).
+// ---------------------------------------------------------------------------
+template <int SRC, int ACT>   // ACT 1: ReLU, 2: LeakyReLU(0.2) -- a compile-time switch: as a run-time one it was compiled to branches per element
+__global__ __launch_bounds__(128) void wino4_out_in_h3_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
+                                                              const float* __restrict__ vs_in, float us,
+                                                              const int32_t* __restrict__ wvalid, float* __restrict__ V,
+                                                              float* __restrict__ vs_out, int W, int C,
+                                                              long ntile_pad_in, long ntile_pad_out, int nseg) {
+  __shared__ float wmax[2][2];
+  const int C4 = C >> 2, c4 = threadIdx.x, wave = threadIdx.x >> 6;
+  const int tw = (W + 3) >> 2;                              // tiles per tile row of layer L
+  // width of layer L + 1's input map and its tiles per line (SRC 2: conv6 has Wn - 1 output columns in tiles of 4)
+  const int Wn = SRC ? W + 1 : W, twn = SRC == 2 ? (Wn - 1 + 3) >> 2 : (Wn + 3) >> 2;
+  const int b = blockIdx.x / nseg, seg = blockIdx.x - b * nseg;
+  const int seglen = (twn + nseg - 1) / nseg;
+  const int tx0 = seg * seglen, tx1 = tx0 + seglen < twn ? tx0 + seglen : twn;
+  if (tx0 >= tx1) return;                                   // (uniform over the workgroup)
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 bs = *(const f32x4*)(bias + c4 * 4);
+  const int wv = wvalid ? (wvalid[b] < W ? wvalid[b] : W) : W;
+  // Buffer addressing (both tensors are below 2 GB: wino4_out_in_ok): one VGPR offset per tile, the component stride in
+  // an SGPR offset -- with 64-bit pointers every one of the 72 accesses of a step cost a 64-bit multiply on the scalar
+  // unit, which a wave that is alone on its SIMD pays in full
+  const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Mo, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, 0x7FFFFFFF, 0x00020000);
+  const unsigned cs_in = (unsigned)(ntile_pad_in * C * 4);                        // bytes per component
+  const unsigned cs_out = (unsigned)(ntile_pad_out * C * 4) * (SRC == 2 ? 2u : 1u);   // (conv6's V: two rows of C per tile)
+  // the 36 products of layer L's tile t (read once: nontemporal); all loads first: the memory parallelism has to come
+  // from inside a thread
+  auto load_tile = [&](long t, f32x4 (&mm)[6][6]) __attribute__((always_inline)) {
+    const unsigned vo = (unsigned)((t * C + c4 * 4) * 4);
+    unsigned so = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+#pragma unroll
+      for (int j = 0; j < 6; j++, so += cs_in)
+        mm[j][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, vo, so, 2));
+  };
+  // A^T m A of that tile (column index tx), scaled, bias, activation, columns from wv on zero
+  auto out_tile = [&](const f32x4 (&mm)[6][6], long t, int tx, f32x4 (&o)[4][4]) __attribute__((always_inline)) {
+    const float rs = vs_in[t] * us;
+    f32x4 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      f32x4 c[4];
+      wino4_at(mm[j], c);
+#pragma unroll
+      for (int k = 0; k < 4; k++) s[k][j] = c[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      wino4_at(s[k], o[k]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int xx = 4 * tx + j;
+        f32x4 v = o[k][j] * rs + bs;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float e = v[c];
+          if (ACT == 1) e = e > 0.f ? e : 0.f;
+          else if (ACT == 2) e = e > 0.f ? e : 0.2f * e;
+          if (xx >= wv) e = 0.f;
+          v[c] = e;
+        }
+        o[k][j] = v;
+      }
+    }
+  };
+  f32x4 prev[4][4], pp3[4], o[4][4];   // tile tx - 1, column 3 of tile tx - 2, tile tx of the next layer's input map
+  f32x4 carry[4];                      // SRC 1: conv column 4 tx - 1, maxima of the four row pairs
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    pp3[r] = z;
+    carry[r] = z;
+#pragma unroll
+    for (int j = 0; j < 4; j++) prev[r][j] = z;
+  }
+  int par = 0;
+  const int txs = tx0 > 0 ? tx0 - 1 : 0;
+  const long trow = SRC == 1 ? (long)b * 2 * tw : (long)b * tw;   // layer L's first tile of this line (SRC 1: of its upper tile row)
+  // The products of a step's tile are requested one step ahead: they are in flight under the input transform of the
+  // step before (a wave has nobody to hide its load latency behind: one wave per SIMD).
+  f32x4 mm[6][6];
+  if (txs < tw) load_tile(trow + txs, mm);
+#pragma unroll 1
+  for (int tx = txs; tx <= tx1; tx++) {
+    const bool more = tx + 1 <= tx1 && tx + 1 < tw;
+    // ---- tile tx of the map (zeros past its last tile)
+    if (SRC == 0) {
+      if (tx < tw) out_tile(mm, trow + tx, tx, o);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) o[r][j] = z;
+      }
+      if (more) load_tile(trow + tx + 1, mm);
+    } else {
+      constexpr int PR = SRC == 1 ? 4 : 2;   // pooled rows
+      f32x4 cm[PR][4];   // [pooled row][column of the tile]: maximum over the two conv rows of the pool window
+      if (SRC == 2) {
+        if (tx < tw) {
+          f32x4 c[4][4];
+          out_tile(mm, trow + tx, tx, c);
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              cm[0][j][e] = fmaxf(c[0][j][e], c[1][j][e]);
+              cm[1][j][e] = fmaxf(c[2][j][e], c[3][j][e]);
+            }
+          if (more) load_tile(trow + tx + 1, mm);
+        } else {
+#pragma unroll
+          for (int r = 0; r < PR; r++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) cm[r][j] = z;
+        }
+      } else if (tx < tw) {
+        f32x4 m1[6][6], c[4][4];
+        load_tile(trow + tw + tx, m1);     // the lower tile row: in flight under the upper tile's transform
+        out_tile(mm, trow + tx, tx, c);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            cm[0][j][e] = fmaxf(c[0][j][e], c[1][j][e]);
+            cm[1][j][e] = fmaxf(c[2][j][e], c[3][j][e]);
+          }
+        if (more) load_tile(trow + tx + 1, mm);
+        out_tile(m1, trow + tw + tx, tx, c);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            cm[PR - 2][j][e] = fmaxf(c[0][j][e], c[1][j][e]);
+            cm[PR - 1][j][e] = fmaxf(c[2][j][e], c[3][j][e]);
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < PR; r++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) cm[r][j] = z;
+      }
+#pragma unroll
+      for (int r = 0; r < PR; r++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int xx = 4 * tx + j;            // pooled column xx = max over conv columns xx - 1 and xx
+          const f32x4 left = j == 0 ? carry[r] : cm[r][j - 1];
+          f32x4 v;
+          if (xx > W) v = z;                    // past the pooled map
+          else if (xx == W) v = left;           // right edge: column W - 1 alone
+          else if (xx == 0) v = cm[r][0];       // left edge: column 0 alone
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(left[e], cm[r][j][e]);
+          }
+          o[r][j] = v;
+        }
+        carry[r] = cm[r][3];
+      }
+    }
+    // ---- conv6's tile tx - 1: pooled columns prev[.][0..3] | o[.][0] of both rows (wino42_in_h3_kernel's arithmetic)
+    if (SRC == 2 && tx > tx0) {
+      f32x4 v[2][5];
+      float mx = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 2; ky++) {
+        const f32x4 d0 = prev[ky][0], d1 = prev[ky][1], d2 = prev[ky][2], d3 = prev[ky][3], d4 = o[ky][0];
+        const f32x4 d31 = d3 - d1;
+        v[ky][0] = 2.f * (d0 - d2) + d31;
+        v[ky][1] = d3 - d2 - 2.f * d1;
+        v[ky][2] = 2.f * d1 - 3.f * d2 + d3;
+        v[ky][3] = d31;
+        v[ky][4] = 2.f * (d1 - d3) - d2 + d4;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_fabsf(v[ky][k][e]));
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      if ((threadIdx.x & 63) == 0) wmax[par][wave] = mx;
+      __syncthreads();
+      mx = fmaxf(mx, wmax[par][wave ^ 1]);
+      par ^= 1;
+      float sc, uns;
+      split_scale_from_max(mx, sc, uns);
+      const long tn = (long)b * twn + tx - 1;
+      if (c4 == 0) vs_out[tn] = uns;
+#pragma unroll
+      for (int ky = 0; ky < 2; ky++) {
+        const unsigned vo = (unsigned)(((tn * 2 + ky) * C + (c4 >> 1) * 8 + (c4 & 1) * 4) * 4);
+        unsigned so = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++, so += cs_out) {
+          uint2 hi, lo;
+          split4(v[ky][k], sc, hi, lo);
+          __builtin_amdgcn_raw_buffer_store_b128(split_pair_chunk(c4, hi, lo), v_rsrc, vo, so, 2);
+        }
+      }
+    }
+    // ---- the next layer's tile tx - 1: patch columns pp3 | prev[.][0..3] | o[.][0]
+    if (SRC != 2 && tx > tx0) {
+      f32x4 u[6][6];
+      float mx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        f32x4 d[6], c[6];
+        d[0] = z;
+        d[5] = z;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          d[r + 1] = j == 0 ? pp3[r] : (j == 5 ? o[r][0] : prev[r][j == 0 || j == 5 ? 0 : j - 1]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) mx = fmaxf(mx, __builtin_fabsf(d[r + 1][e]));
+        }
+        wino4_bt(d, c);
+#pragma unroll
+        for (int k = 0; k < 6; k++) u[k][j] = c[k];
+      }
+      for (int off = 1; off < C4 && off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      if (C4 > 64) {
+        if ((threadIdx.x & 63) == 0) wmax[par][wave] = mx;
+        __syncthreads();
+        mx = fmaxf(mx, wmax[par][wave ^ 1]);
+        par ^= 1;
+      }
+      float sc, uns;
+      split_scale_from_max(49.f * mx, sc, uns);   // (the bound wino4_in_h3_kernel uses)
+      const long tn = (long)b * twn + tx - 1;
+      if (c4 == 0) vs_out[tn] = uns;
+      // (store_split_pair's layout: the even lane of a pair stores the 16-byte hi chunk of 8 channels, the odd lane the lo chunk)
+      const unsigned vo = (unsigned)((tn * C + (c4 >> 1) * 8 + (c4 & 1) * 4) * 4);
+      unsigned so = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        f32x4 v[6];
+        wino4_bt(u[k], v);
+#pragma unroll
+        for (int j = 0; j < 6; j++, so += cs_out) {
+          uint2 hi, lo;
+          split4(v[j], sc, hi, lo);
+          __builtin_amdgcn_raw_buffer_store_b128(split_pair_chunk(c4, hi, lo), v_rsrc, vo, so, 2);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < (SRC == 2 ? 2 : 4); r++) {
+      pp3[r] = prev[r][3];
+#pragma unroll
+      for (int j = 0; j < 4; j++) prev[r][j] = o[r][j];
+    }
+  }
+}
+
+// src 0: layer L's map is 4 rows high and feeds layer L + 1 directly; 1: 8 rows high, MaxPool (2,2)/(2,1)/pad (0,1) between;
+// 2: 4 rows high, that pool, then conv6's F(4,2) (C = 512 only, as wino42_in_h3_kernel)
+bool wino4_out_in_ok(int B, int H, int W, int C, int src) {
+  if (src == 2)
+    return C == 512 && H == 4 && W >= 4 && B >= 1 && 36.0 * (double)wino4_pad(wino4_tiles(B, H, W)) * C * 4.0 < 2.0e9 &&
+           5.0 * (double)wino4_pad((long)B * ((W + 3) / 4)) * 2 * C * 4.0 < 2.0e9;
+  return (C == 256 || C == 512) && H == (src ? 8 : 4) && W >= 4 && B >= 1 &&
+         36.0 * (double)wino4_pad(wino4_tiles(B, H, W)) * C * 4.0 < 2.0e9 &&
+         36.0 * (double)wino4_pad(wino4_tiles(B, 4, src ? W + 1 : W)) * C * 4.0 < 2.0e9;   // (32-bit buffer offsets)
+}
+void launch_wino4_out_in(const float* M, const float* bias, const float* vs_in, float us, const int32_t* wvalid, float* V,
+                         float* vs_out, int B, int H, int W, int C, int act, int src, hipStream_t s) {
+  const int Wn = src ? W + 1 : W, twn = src == 2 ? (Wn - 1 + 3) / 4 : (Wn + 3) / 4;
+  static const int nseg_env = getenv("CRNN_WINO4_CHAIN_NSEG") ? atoi(getenv("CRNN_WINO4_CHAIN_NSEG")) : 0;
+  // 256 lines: two segments of two-wave workgroups (C = 512) are one wave per SIMD over the chip; for the one-wave
+  // workgroups of C = 256 three segments measured best (conv3 -> conv4: 0.123 ms against 0.133 with four, 0.139 with two)
+  int nseg = nseg_env > 0 ? nseg_env : (C == 512 ? 2 : 3);
+  if (nseg > twn) nseg = twn;
+  const long tp_in = wino4_pad(wino4_tiles(B, H, W));
+  const long tp_out = src == 2 ? wino4_pad((long)B * twn) : wino4_pad(wino4_tiles(B, 4, Wn));
+  const dim3 g(B * nseg), bl(C / 4);
+  if (src == 2 && act == 1) hipLaunchKernelGGL((wino4_out_in_h3_kernel<2, 1>), g, bl, 0, s, M, bias, vs_in, us, wvalid, V, vs_out, W, C, tp_in, tp_out, nseg);
+  else if (src == 2) hipLaunchKernelGGL((wino4_out_in_h3_kernel<2, 2>), g, bl, 0, s, M, bias, vs_in, us, wvalid, V, vs_out, W, C, tp_in, tp_out, nseg);
+  else if (src && act == 1) hipLaunchKernelGGL((wino4_out_in_h3_kernel<1, 1>), g, bl, 0, s, M, bias, vs_in, us, wvalid, V, vs_out, W, C, tp_in, tp_out, nseg);
+  else if (src) hipLaunchKernelGGL((wino4_out_in_h3_kernel<1, 2>), g, bl, 0, s, M, bias, vs_in, us, wvalid, V, vs_out, W, C, tp_in, tp_out, nseg);
+  else if (act == 1) hipLaunchKernelGGL((wino4_out_in_h3_kernel<0, 1>), g, bl, 0, s, M, bias, vs_in, us, wvalid, V, vs_out, W, C, tp_in, tp_out, nseg);
+  else hipLaunchKernelGGL((wino4_out_in_h3_kernel<0, 2>), g, bl, 0, s, M, bias, vs_in, us, wvalid, V, vs_out, W, C, tp_in, tp_out, nseg);
+}
+
 // The 36 GEMMs M[c] = V[c] U[c]^T as ONE persistent launch.  Work unit = (component, 128 tiles, TBN channels),
 // K = Cin; unit u = (component * ntm + m-tile) * ntn + n-tile.  Block L takes units L, L + G, L + 2G, ...:
 // the launch is G = one block per CU slot, every block gets the same number of units (+-1) -- no partly filled

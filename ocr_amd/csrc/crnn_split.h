@@ -65,6 +65,16 @@ __device__ __forceinline__ void split4(f32x4 v, float s, uint2& hi, uint2& lo) {
 }
 // lanes 2i / 2i+1 hold channels [8g, 8g+4) / [8g+4, 8g+8) of one row: the even lane stores the 16-byte hi chunk, the
 // odd lane the 16-byte lo chunk (one 16-byte store per lane, as in the fp32 form)
+// the 16 bytes the lane stores: lanes trade halves so that the even lane has the hi chunk, the odd lane the lo chunk
+__device__ __forceinline__ i32x4 split_pair_chunk(int c4, uint2 hi, uint2 lo) {
+  const bool odd = c4 & 1;
+  const uint2 send = odd ? hi : lo;
+  uint2 recv;
+  recv.x = (unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
+  recv.y = (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+  const uint4 out = odd ? uint4{recv.x, recv.y, lo.x, lo.y} : uint4{hi.x, hi.y, recv.x, recv.y};
+  return i32x4{(int)out.x, (int)out.y, (int)out.z, (int)out.w};
+}
 __device__ __forceinline__ void store_split_pair(float* rowbase, int c4, uint2 hi, uint2 lo) {
   const bool odd = c4 & 1;
   const uint2 send = odd ? hi : lo;

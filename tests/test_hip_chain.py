@@ -1,0 +1,94 @@
+"""GPU: the chained transform kernel (wino4_out_in_h3_kernel: a layer's Winograd output transform and the next
+layer's input transform in one launch: conv3 -> pool2 -> conv4, conv4 -> conv5, conv5 -> pool3 -> conv6) against
+the kernels it replaces.
+
+The chained kernel performs the same operations on the same values, so everything downstream must be
+BIT-identical with it on (default) and off (CRNN_WINO4_CHAIN=0, read per call).  It only runs from 128 lines
+up, so these batches are larger than the ones the stage-by-stage oracle tests use; the 256-line tests of
+tests/test_hip_scale.py pin the same path to the reference's strings."""
+import os
+
+import numpy as np
+import pytest
+
+from ocr_amd.crnn import keys
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zh(synth_zh):
+    from ocr_amd.crnn.network_hip import CRNN
+    m = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, lanes=1)
+    m.load_state_dict(synth_zh)
+    return m
+
+
+def _with_chain(value, fn):
+    old = os.environ.pop("CRNN_WINO4_CHAIN", None)
+    if value is not None:
+        os.environ["CRNN_WINO4_CHAIN"] = value
+    try:
+        return fn()
+    finally:
+        os.environ.pop("CRNN_WINO4_CHAIN", None)
+        if old is not None:
+            os.environ["CRNN_WINO4_CHAIN"] = old
+
+
+# (lines, width, ragged): 280 -> 18 tiles per row in conv3 and conv4 (two tile rows / one); 288 -> conv3's width
+# is a multiple of 4, so pool2's last column lies past conv3's last tile (19 tiles in conv4); 200 with ragged
+# valid widths -> the width masks of both layers; 132 -> an odd tile count and a short last segment
+CASES = [(256, 280, False), (128, 288, False), (130, 200, True), (160, 132, True)]
+
+
+@pytest.mark.parametrize("n,w,ragged", CASES)
+def test_chained_transforms_are_bit_identical_to_the_separate_kernels(zh, n, w, ragged):
+    rs = np.random.RandomState(n + w)
+    x = (rs.randint(0, 256, size=(n, 32, w)).astype(np.float32) / 255.0 - 0.5) / 0.5
+    widths = None
+    if ragged:
+        widths = rs.randint(max(8, w // 3), w + 1, size=n).astype(np.int32)
+        widths[0] = w
+        for i in range(n):
+            x[i, :, widths[i]:] = 0.0
+    for stage in (5, 6, 10):
+        off = _with_chain("0", lambda: zh.debug_stage(x, stage, widths))
+        on = _with_chain(None, lambda: zh.debug_stage(x, stage, widths))
+        assert np.isfinite(off).all()
+        assert np.array_equal(off, on), "stage %d differs with all chained kernels" % stage
+        for mask, what in (("0x8", "conv3 -> conv4"), ("0x10", "conv4 -> conv5"), ("0x20", "conv5 -> conv6")):
+            one = _with_chain(mask, lambda: zh.debug_stage(x, stage, widths))
+            assert np.array_equal(off, one), "stage %d differs with %s chained" % (stage, what)
+
+
+def test_stage_requests_get_the_stage_written(zh):
+    """crnn_debug_stage(3) / (4) / (5) ask for exactly the activations the chained kernels never write: the
+    request turns the one kernel in question off and the stage comes back as with CRNN_WINO4_CHAIN=0."""
+    rs = np.random.RandomState(3)
+    x = (rs.randint(0, 256, size=(128, 32, 280)).astype(np.float32) / 255.0 - 0.5) / 0.5
+    for stage in (3, 4, 5):
+        off = _with_chain("0", lambda: zh.debug_stage(x, stage))
+        on = _with_chain(None, lambda: zh.debug_stage(x, stage))
+        assert np.abs(off).max() > 0
+        assert np.array_equal(off, on)
+
+
+def test_chained_kernels_run_in_the_default_path(zh):
+    """The per-launch names of a 256-line batch show the chained kernels (and not the ones they replace)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    lines = torch.randint(0, 256, (256, 32, 280), dtype=torch.uint8, device=dev)
+    T = 71
+    lab = torch.zeros((256, T), dtype=torch.int32, device=dev)
+    ln = torch.zeros((256,), dtype=torch.int32, device=dev)
+    zh.set_profiling(True)
+    try:
+        zh.forward_device(lines.data_ptr(), 256, 280, lab.data_ptr(), ln.data_ptr())
+        zh.synchronize()
+        names = [k[0] for k in zh.kernel_times()]
+    finally:
+        zh.set_profiling(False)
+    assert "conv3_wout4_pool2_win4" in names and "conv4_wout4_win4" in names and "conv5_wout4_pool3_win4" in names
+    for gone in ("conv4_win4", "conv5_win4", "conv6_win4", "conv3_wout4_pool2", "conv4_wout4", "conv5_wout4_pool3"):
+        assert gone not in names
