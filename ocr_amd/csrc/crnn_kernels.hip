@@ -484,6 +484,13 @@ __global__ __launch_bounds__(256) void wino4_out_pool21_kernel(const float* __re
 // bit-identical to theirs (tests/test_hip_chain.py).  A segment computes the tile before and the tile after its own for
 // their edge columns (two segments: 11 % more M reads).  Few threads, but each has 36 independent 16-byte loads in
 // flight per step, and with one wave per SIMD (400-480 registers) the chip still has ~35 MB on the way.
+// What bounds it (conv4 -> conv5, 256 lines): 0.162 ms; 0.10 with the stores ablated, 0.10 with the loads ablated, 0.06
+// with both -- compute, load latency and store acknowledgement add up instead of overlapping.  The compiler waits for
+// a step's loads with vmcnt(0): with loads AND stores pending it assumes they may complete out of order, so the wait
+// also covers the 36 stores issued just before.  Hence plain stores, not the nontemporal ones of the separate input
+// transform: the L2 acknowledges them sooner (0.156 -> 0.134 ms; conv3 -> conv4 0.123 -> 0.114).  Tried and dropped:
+// loads as inline asm with hand-written vmcnt(36) waits (the register allocator moves the "loaded" values before
+// they arrive: memory faults), the tile staged through LDS by direct-to-LDS loads with exact waits (correct, 0.152 ms).
 // SRC 2 is conv5 -> pool3 -> conv6: the map is 4 rows high, the pool leaves 2, and the next layer is the 1-D F(4,2)
 // of wino42_in_h3_kernel (tile tx - 1 = pooled columns 4 (tx - 1) .. 4 tx of both rows; scale = the exact maximum).
 // ---------------------------------------------------------------------------
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(128) void wino4_out_in_h3_kernel(const float* __res
         for (int k = 0; k < 5; k++, so += cs_out) {
           uint2 hi, lo;
           split4(v[ky][k], sc, hi, lo);
-          __builtin_amdgcn_raw_buffer_store_b128(split_pair_chunk(c4, hi, lo), v_rsrc, vo, so, 2);
+          __builtin_amdgcn_raw_buffer_store_b128(split_pair_chunk(c4, hi, lo), v_rsrc, vo, so, 0);
         }
       }
     }
@@ -729,7 +736,7 @@ __global__ __launch_bounds__(128) void wino4_out_in_h3_kernel(const float* __res
         for (int j = 0; j < 6; j++, so += cs_out) {
           uint2 hi, lo;
           split4(v[j], sc, hi, lo);
-          __builtin_amdgcn_raw_buffer_store_b128(split_pair_chunk(c4, hi, lo), v_rsrc, vo, so, 2);
+          __builtin_amdgcn_raw_buffer_store_b128(split_pair_chunk(c4, hi, lo), v_rsrc, vo, so, 0);
         }
       }
     }

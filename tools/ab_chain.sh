@@ -9,9 +9,5 @@ run() { # name, env...
 for rep in 1 2; do
 run off_$rep CRNN_WINO4_CHAIN=0
 run on_$rep CRNN_X=1
-run only3_$rep CRNN_WINO4_CHAIN=0x8
-run only4_$rep CRNN_WINO4_CHAIN=0x10
-run only5_$rep CRNN_WINO4_CHAIN=0x20
 run m30_$rep CRNN_WINO4_CHAIN=0x30
-run nseg3_$rep CRNN_WINO4_CHAIN_NSEG=3
 done
