@@ -39,7 +39,8 @@ def _with_chain(value, fn):
 # (lines, width, ragged): 280 -> 18 tiles per row in conv3 and conv4 (two tile rows / one); 288 -> conv3's width
 # is a multiple of 4, so pool2's last column lies past conv3's last tile (19 tiles in conv4); 200 with ragged
 # valid widths -> the width masks of both layers; 132 -> an odd tile count and a short last segment
-CASES = [(256, 280, False), (128, 288, False), (130, 200, True), (160, 132, True)]
+# 512 lines: twice the headline batch, tensors near the 32-bit offset limit of the kernel's buffer addressing
+CASES = [(256, 280, False), (128, 288, False), (130, 200, True), (160, 132, True), (512, 280, False)]
 
 
 @pytest.mark.parametrize("n,w,ragged", CASES)
@@ -60,6 +61,28 @@ def test_chained_transforms_are_bit_identical_to_the_separate_kernels(zh, n, w, 
         for mask, what in (("0x8", "conv3 -> conv4"), ("0x10", "conv4 -> conv5"), ("0x20", "conv5 -> conv6")):
             one = _with_chain(mask, lambda: zh.debug_stage(x, stage, widths))
             assert np.array_equal(off, one), "stage %d differs with %s chained" % (stage, what)
+
+
+def test_leaky_relu_and_dense_head_variants(synth_en):
+    """LeakyReLU(0.2) is a compile-time variant of the chained kernels; the dense head (lstmFlag=False) shares the conv
+    stack: both bit-identical with the kernels on and off, ragged widths."""
+    from ocr_amd.crnn.network_hip import CRNN
+    from ocr_amd.crnn.synth import synth_state_dict
+    rs = np.random.RandomState(11)
+    n, w = 144, 240
+    x = (rs.randint(0, 256, size=(n, 32, w)).astype(np.float32) / 255.0 - 0.5) / 0.5
+    widths = rs.randint(60, w + 1, size=n).astype(np.int32)
+    for i in range(n):
+        x[i, :, widths[i]:] = 0.0
+    leaky = CRNN(32, 1, 65, 256, leakyRelu=True, lstmFlag=True, GPU=True, alphabet=keys.alphabetEnglish, lanes=1)
+    leaky.load_state_dict(synth_en)
+    dense = CRNN(32, 1, 65, 256, leakyRelu=False, lstmFlag=False, GPU=True, alphabet=keys.alphabetEnglish, lanes=1)
+    dense.load_state_dict(synth_state_dict(65, seed=0, lstm=False))
+    for m in (leaky, dense):
+        off = _with_chain("0", lambda: m.debug_stage(x, 10, widths))
+        on = _with_chain(None, lambda: m.debug_stage(x, 10, widths))
+        assert np.isfinite(off).all() and np.abs(off).max() > 0
+        assert np.array_equal(off, on)
 
 
 def test_stage_requests_get_the_stage_written(zh):
