@@ -112,6 +112,10 @@ struct crnn_handle {
   float wih_us[2] = {1.f, 1.f}, emb0_us = 1.f;
   uint16_t* d_wih_h3[2] = {};
   uint16_t* d_emb0_h3 = nullptr;
+  // ... and conv0 inside conv0_win4_h3_kernel (CRNN_CONV0_MFMA=0: its scalar fp32 form): [64][16] taps, nine used
+  std::vector<uint16_t> h_conv0_h3;
+  float conv0_us3 = 1.f;   // 1 / (2^14 s_weights): the kernel scales the pixels by 2^14
+  uint16_t* d_conv0_h3 = nullptr;
   // ... and the recurrence (lstm_rec_h3_kernel; CRNN_REC_H3=0 keeps the f32 MFMA kernel)
   bool rec_h3 = true;
   std::vector<uint16_t> h_whh3[2];
@@ -329,6 +333,7 @@ int ensure_device(crnn_handle* h, bool need_weights = true) {
     for (int l = 0; l < 2; l++)
       if ((rc = upload16(h, h->h_whh3[l], &h->d_whh3[l]))) return rc;
     if ((rc = upload16(h, h->h_emb0_h3, &h->d_emb0_h3))) return rc;
+    if ((rc = upload16(h, h->h_conv0_h3, &h->d_conv0_h3))) return rc;
     if ((rc = upload(h, h->h_cls_wnorm, &h->d_cls_wnorm))) return rc;
     for (int l = 0; l < 2; l++) {
       if ((rc = upload16(h, h->hb_wih[l], &h->db_wih[l]))) return rc;
@@ -692,7 +697,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   static const bool c0f = !(getenv("CRNN_CONV0_FUSED") && atoi(getenv("CRNN_CONV0_FUSED")) == 0);
   const bool fuse0 = c0f && !tl_cur->want_p0 && conv1_on_wino4_h3(h, n) && p.wv && p.wm && p.vs && g.W % 2 == 0;
   if (fuse0) {
-    launch_conv0_win4(p.x, h->d_conv_w[0], h->d_conv_b[0], p.wv, p.vs, m_p0, n, g.W, act, s);
+    launch_conv0_win4(p.x, h->d_conv_w[0], h->d_conv_b[0], p.wv, p.vs, m_p0, n, g.W, act, s, h->d_conv0_h3, h->conv0_us3);
     kmark(h, "conv0_pool0_win4", 2.0 * dn * 32 * g.W * 64 * 9, 4.0 * dn * 32 * g.W + 4.0 * 36.0 * wino4_tiles(n, 16, g.W1) * 64);
   } else {
     if (b16) launch_conv0_pool_bf16(p.x, h->d_conv_w[0], h->d_conv_b[0], p.p0, m_p0, n, g.W, act, s);
@@ -1239,6 +1244,17 @@ int crnn_load_weights(crnn_handle* h, const crnn_tensor* tensors, int32_t n) {
       h->wino4_us[i] = to_f16x3_host(h->h_wino4[i].data(), h->h_wino4[i].size(), h->h_wino4h[i].data());
       std::vector<float>().swap(h->h_wino4[i]);     // only the split form is used
     }
+  h->h_conv0_h3.clear();
+  {
+    static const bool c0m = !(getenv("CRNN_CONV0_MFMA") && atoi(getenv("CRNN_CONV0_MFMA")) == 0);
+    if (h->h3 && c0m) {
+      std::vector<float> w16((size_t)64 * 16, 0.f);   // [channel][tap], taps 9 .. 15 zero (one K = 16 MFMA step)
+      for (int o = 0; o < 64; o++)
+        for (int t = 0; t < 9; t++) w16[(size_t)o * 16 + t] = h->h_conv_w[0][(size_t)t * 64 + o];
+      h->h_conv0_h3.resize(w16.size() * 2);
+      h->conv0_us3 = to_f16x3_host(w16.data(), w16.size(), h->h_conv0_h3.data()) * (1.f / 16384.f);
+    }
+  }
   if (h->cfg.lstm) {
     for (int l = 0; l < 2; l++) {
       h->h_whhp[l].resize((size_t)2 * 4 * nh * nh);
@@ -1770,6 +1786,7 @@ void crnn_destroy(crnn_handle* h) {
     for (int l = 0; l < 2; l++) (void)hipFree(h->d_wih_h3[l]);
     for (int l = 0; l < 2; l++) (void)hipFree(h->d_whh3[l]);
     (void)hipFree(h->d_emb0_h3);
+    (void)hipFree(h->d_conv0_h3);
     (void)hipFree(h->d_cls_wnorm);
     for (int i = 0; i < 7; i++) (void)hipFree(h->db_conv_w[i]);
     for (int l = 0; l < 2; l++) { (void)hipFree(h->db_wih[l]); (void)hipFree(h->db_whhp[l]); (void)hipFree(h->db_emb_w[l]); }

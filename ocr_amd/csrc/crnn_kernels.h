@@ -183,7 +183,8 @@ struct Wino4Gemm {
 bool wino4_gemm_uses_pp(const Wino4Gemm& p);   // this launch runs wino4_gemm_h3_pp_kernel (else the loader-wave / plain form)
 // conv0 + activation + pool0 + conv1's F(4x4) input transform (f16x3 V, per-tile scales) in one kernel; in: [B,32,W] fp32
 void launch_conv0_win4(const float* in, const float* w9x64, const float* bias, float* V, float* vs,
-                       const int32_t* w1valid, int B, int W, int act, hipStream_t s);
+                       const int32_t* w1valid, int B, int W, int act, hipStream_t s, const uint16_t* w3 = nullptr,
+                       float us3 = 1.f);   // w3: conv0's weights as f16x3 [64][16] taps -> conv0 on the fp16 MFMA
 // F(4x4,3x3) GEMMs + output transform in one kernel (wino4_fused_h3_kernel; f16x3 operands only)
 struct Wino4Fused {
   const float* V;      // [36][ntile_pad][Cin], f16x3

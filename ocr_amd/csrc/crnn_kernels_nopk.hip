@@ -23,16 +23,29 @@ namespace crnn {
 // CU); phase 2 is wino4_in_h3_kernel reading its 6 x 6 patches from LDS: thread = (tile, 4 channels), the tile's
 // scale from the 16 lanes that share it.  Rows -1 and 16 and columns outside [0, min(W/2, w1valid)) are zeros.
 // ---------------------------------------------------------------------------
+// MF (round 3, CRNN_CONV0_MFMA, default on): phase 1 on the fp16 MFMA in the f16x3 form instead of 2592 scalar FMAs per
+// thread (this file has no packed fp32).  The conv is a GEMM with K = 9: M = the 1152 conv positions of the block ordered
+// (pooled pixel, position in its 2x2 window), N = 64 channels, the nine taps padded to one K = 16 step of
+// v_mfma_f32_32x32x16_f16 -- the positions as FIRST operand, so a lane ends with the four window positions of two
+// pooled pixels for one channel and the pool is three v_max in registers.  The window sits in LDS as (hi, lo) fp16
+// planes (scale 2^14: |x| <= 1), the weights as (hi, lo) fragments in registers (w3: [64][16] in to_f16x3_host's layout,
+// us3 = 1 / (2^14 s_weights)); 6 MFMAs per 32 positions.  The kernel is VALU-bound: 0.129 -> 0.114 ms (what remains
+// is phase 2, the same transform + split work as a whole wino4_in_h3_kernel launch).
 constexpr int C0_TXB = 4, C0_PC = 4 * C0_TXB + 2;
+typedef _Float16 f16x8n __attribute__((ext_vector_type(8)));
+typedef float f32x16n __attribute__((ext_vector_type(16)));
+template <bool MF>
 __global__ __launch_bounds__(256, 2) void conv0_win4_h3_kernel(const float* __restrict__ in,
                                                                const float* __restrict__ w9x64,
                                                                const float* __restrict__ bias, float* __restrict__ V,
                                                                float* __restrict__ vs,
                                                                const int32_t* __restrict__ w1valid, int B, int W,
-                                                               int act, long ntile_pad) {
+                                                               int act, long ntile_pad,
+                                                               const uint16_t* __restrict__ w3, float us3) {
   constexpr int IC = 2 * C0_PC + 4;   // input window: columns 2 x1base - 1 ... 2 (x1base + C0_PC - 1) + 2, padded to 40
   __shared__ __attribute__((aligned(16))) float P[16 * C0_PC * 64];
-  __shared__ __attribute__((aligned(16))) float I[34 * IC];
+  __shared__ __attribute__((aligned(16))) float I[MF ? 4 : 34 * IC];
+  __shared__ __attribute__((aligned(16))) _Float16 Ih[MF ? 34 * IC : 8], Il[MF ? 34 * IC : 8];
   const int W1 = W >> 1, ntx = (W1 + 3) >> 2, ngrp = (ntx + C0_TXB - 1) / C0_TXB;
   const int cg = threadIdx.x & 15, sub = threadIdx.x >> 4;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -47,11 +60,68 @@ __global__ __launch_bounds__(256, 2) void conv0_win4_h3_kernel(const float* __re
     for (int i = threadIdx.x; i < 34 * IC; i += 256) {
       const int r = i / IC, c = i - r * IC;
       const int yy = r - 1, xx = 2 * x1base - 1 + c;
-      I[i] = ((unsigned)yy < 32u && (unsigned)xx < (unsigned)W) ? ip[yy * W + xx] : 0.f;
+      const float v = ((unsigned)yy < 32u && (unsigned)xx < (unsigned)W) ? ip[yy * W + xx] : 0.f;
+      if (MF) {
+        const float x = v * 16384.f;
+        const _Float16 hi = (_Float16)x;
+        Ih[i] = hi;
+        Il[i] = (_Float16)(x - (float)hi);
+      } else {
+        I[i] = v;
+      }
     }
     __syncthreads();
     // ---- phase 1: pooled conv0 pixels into LDS
-    {
+    if (MF) {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i32 = lane & 31, kg = lane >> 5;
+      f16x8n wh[2], wl[2];
+      float bsl[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; nb++) {
+        const uint4* wp = (const uint4*)(w3 + ((nb * 32 + i32) * 32 + kg * 16));
+        wh[nb] = __builtin_bit_cast(f16x8n, wp[0]);
+        wl[nb] = __builtin_bit_cast(f16x8n, wp[1]);
+        bsl[nb] = bias[nb * 32 + i32];
+      }
+      // the lane's eight k: taps (ky, kx) = 0..7 for the low half of the wave, tap 8 and seven zeros for the high half
+      int toff[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) toff[t] = kg ? 2 * IC + 2 : (t / 3) * IC + t % 3;
+      const int e = i32 & 3;
+#pragma unroll 1
+      for (int mb = wave; mb < 2 * C0_PC; mb += 4) {   // 16 * C0_PC / 8 blocks of 8 pooled pixels = 32 positions
+        const int pp = 8 * mb + (i32 >> 2);
+        const int y1 = pp / C0_PC, jx = pp - y1 * C0_PC;
+        const int base = (2 * y1 + (e >> 1)) * IC + 2 * jx + (e & 1);   // (input row 2 y1 - 1 + dy, column 2 x1 - 1 + dx)
+        f16x8n xh, xl;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+          const bool on = !kg || t == 0;
+          xh[t] = on ? Ih[base + toff[t]] : (_Float16)0;
+          xl[t] = on ? Il[base + toff[t]] : (_Float16)0;
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) {
+          f32x16n acc;
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[r] = 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[nb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[nb], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[nb], acc, 0, 0, 0);
+          // acc[4 g + w] = position 8 g + 4 kg + w of the block = window position w of pooled pixel 2 g + kg, channel i32
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const int po = 8 * mb + 2 * g + kg;
+            const int jo = po % C0_PC, x1 = x1base + jo;
+            float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) * us3 + bsl[nb];
+            if (act == 1) v = v > 0.f ? v : 0.f;
+            else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+            if ((unsigned)x1 >= (unsigned)wlim) v = 0.f;
+            P[po * 64 + nb * 32 + i32] = v;
+          }
+        }
+      }
+    } else {
       f32x4 wr[9];
 #pragma unroll
       for (int t = 0; t < 9; t++) wr[t] = *(const f32x4*)(w9x64 + t * 64 + cg * 4);
@@ -151,11 +221,15 @@ __global__ __launch_bounds__(256, 2) void conv0_win4_h3_kernel(const float* __re
 }
 
 void launch_conv0_win4(const float* in, const float* w9x64, const float* bias, float* V, float* vs,
-                       const int32_t* w1valid, int B, int W, int act, hipStream_t s) {
+                       const int32_t* w1valid, int B, int W, int act, hipStream_t s, const uint16_t* w3, float us3) {
   const int W1 = W >> 1, ntx = (W1 + 3) >> 2, ngrp = (ntx + C0_TXB - 1) / C0_TXB;
   const long blocks = (long)B * ngrp;
-  hipLaunchKernelGGL(conv0_win4_h3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, w9x64, bias, V, vs, w1valid, B, W,
-                     act, wino4_pad(wino4_tiles(B, 16, W1)));
+  if (w3)
+    hipLaunchKernelGGL(conv0_win4_h3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, in, w9x64, bias, V, vs, w1valid,
+                       B, W, act, wino4_pad(wino4_tiles(B, 16, W1)), w3, us3);
+  else
+    hipLaunchKernelGGL(conv0_win4_h3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, in, w9x64, bias, V, vs, w1valid,
+                       B, W, act, wino4_pad(wino4_tiles(B, 16, W1)), w3, us3);
 }
 
 constexpr int CLS_MAXCH = 16;   // chunks of 512 classes a row may have (N <= 8192)

@@ -115,3 +115,53 @@ def test_chained_kernels_run_in_the_default_path(zh):
     assert "conv3_wout4_pool2_win4" in names and "conv4_wout4_win4" in names and "conv5_wout4_pool3_win4" in names
     for gone in ("conv4_win4", "conv5_win4", "conv6_win4", "conv3_wout4_pool2", "conv4_wout4", "conv5_wout4_pool3"):
         assert gone not in names
+
+
+def test_conv0_on_the_mfma_against_its_scalar_form(synth_zh):
+    """conv0 inside conv0_win4_h3_kernel runs on the fp16 MFMA in the f16x3 form (CRNN_CONV0_MFMA, read at load);
+    its scalar fp32 form is one environment variable away.  Stage 1 (conv1 + pool1, the first tensor downstream
+    of the fused kernel) must agree to fp32 rounding and the logits to the 1e-3 budget (two fp32-accurate evaluations
+    of a network that amplifies rounding ~1000x differ by a few 1e-4), arg-max sequences equal away from
+    near-ties -- ragged widths included (the kernel masks pooled columns)."""
+    import subprocess
+    import sys
+    import json
+    child = r"""
+import json, sys, os, numpy as np
+sys.path.insert(0, %r)
+from ocr_amd.crnn import keys
+from ocr_amd.crnn.network_hip import CRNN
+from ocr_amd.crnn.synth import synth_state_dict
+rs = np.random.RandomState(21)
+n, w = 96, 280
+x = (rs.randint(0, 256, size=(n, 32, w)).astype(np.float32) / 255.0 - 0.5) / 0.5
+widths = rs.randint(40, w + 1, size=n).astype(np.int32); widths[0] = w
+for i in range(n): x[i, :, widths[i]:] = 0.0
+m = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, lanes=1)
+m.load_state_dict(synth_state_dict(5530, seed=0))
+s1 = m.debug_stage(x, 1, widths); lg = m.debug_stage(x, 10, widths)
+np.savez(sys.argv[1], s1=s1, lg=lg)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, val in (("mfma", None), ("scalar", "0")):
+            e = dict(os.environ)
+            e.pop("CRNN_CONV0_MFMA", None)
+            if val is not None:
+                e["CRNN_CONV0_MFMA"] = val
+            f = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", child, f], env=e, capture_output=True, text=True, timeout=240)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out[tag] = dict(np.load(f))
+    a, b = out["mfma"], out["scalar"]
+    scale = np.abs(b["s1"]).max()
+    err1 = np.abs(a["s1"] - b["s1"]).max() / scale
+    errl = np.abs(a["lg"] - b["lg"]).max()
+    print("conv0 mfma vs scalar: stage 1 rel %.2e, logits abs %.2e" % (err1, errl))
+    assert err1 < 2e-6
+    assert errl < 1e-3
+    top2 = np.sort(b["lg"], axis=-1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 2e-3          # rows whose winner is not a near-tie
+    assert clear.mean() > 0.99
+    assert np.array_equal(a["lg"].argmax(-1)[clear], b["lg"].argmax(-1)[clear])

@@ -250,6 +250,8 @@ int main(int argc, char** argv) {
     launch_conv_gemm_bf16(cq, 2, s1);        // approximate logits, fp16, once
     hipStreamSynchronize(s1);
   }
+  uint16_t* w3 = nullptr;
+  float us3 = 1.f;
   auto victim = [&](float* Vout) {
     if (unfused == 2) {
       launch_cls_select(cL, cA, cW, cbias, canorm, cwnorm, (int32_t*)Vout, CM, CN, CK, cldl, s1, 1, cwnmax);
@@ -257,9 +259,18 @@ int main(int argc, char** argv) {
       launch_conv0_pool(in, w9, bias, p0, nullptr, B, W, 1, s1);
       launch_wino4_in(p0, Vout, B, 16, W1, 64, s1, vs);
     } else {
-      launch_conv0_win4(in, w9, bias, Vout, vs, nullptr, B, W, 1, s1);
+      launch_conv0_win4(in, w9, bias, Vout, vs, nullptr, B, W, 1, s1, w3, us3);   // the product form: conv0 on the fp16 MFMA
     }
   };
+  {
+    std::vector<float> w16f((size_t)64 * 16, 0.f);
+    for (int o = 0; o < 64; o++)
+      for (int t = 0; t < 9; t++) w16f[(size_t)o * 16 + t] = hw[(size_t)t * 64 + o];
+    std::vector<uint16_t> w3h(w16f.size() * 2);
+    us3 = to_f16x3_host(w16f.data(), w16f.size(), w3h.data()) * (1.f / 16384.f);
+    hipMalloc(&w3, w3h.size() * 2);
+    hipMemcpy(w3, w3h.data(), w3h.size() * 2, hipMemcpyHostToDevice);
+  }
   hipMemcpy(in, hin.data(), hin.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(w9, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(bias, hb.data(), 256, hipMemcpyHostToDevice);
