@@ -40,7 +40,9 @@ def _with_chain(value, fn):
 # is a multiple of 4, so pool2's last column lies past conv3's last tile (19 tiles in conv4); 200 with ragged
 # valid widths -> the width masks of both layers; 132 -> an odd tile count and a short last segment
 # 512 lines: twice the headline batch, tensors near the 32-bit offset limit of the kernel's buffer addressing
-CASES = [(256, 280, False), (128, 288, False), (130, 200, True), (160, 132, True), (512, 280, False)]
+# 16 / 24 / 40: one or two tiles per row -- segments shorter than the segment count, the first tile also the last
+CASES = [(256, 280, False), (128, 288, False), (130, 200, True), (160, 132, True), (512, 280, False), (128, 16, False),
+         (136, 24, True), (128, 40, True)]
 
 
 @pytest.mark.parametrize("n,w,ragged", CASES)
