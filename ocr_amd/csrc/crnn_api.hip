@@ -417,7 +417,7 @@ struct Plan {
   float *wv, *wm; // Winograd V[16][tiles][Cin] and Mo[16][tiles][Cout] (largest enabled layer)
   float *vs, *vs2; // f16x3: per-tile unscale factors of the current layer's V (largest tile count); vs2: of the next
                    // layer's V while a chained transform kernel (wino4_out_in_h3_kernel) still reads this layer's
-  float *a3, *rs; // f16x3 copy of a plain GEMM's A operand [n*T][512] and its per-128-row unscale factors
+  float *a3, *rs; // f16x3 copy of a plain GEMM's A operand [n*T][512] and its per-32-row unscale factors
   int32_t* pidx;
   size_t bytes;
 };
@@ -483,7 +483,7 @@ Plan make_plan(const crnn_handle* h, const Geo& g, char* base) {
     p.vs = take(tmax);
     p.vs2 = take(tmax);
     p.a3 = take(h->h3 && h->cfg.lstm ? n * g.T * 512 : 0);
-    p.rs = take(h->h3 && h->cfg.lstm ? (n * g.T + 127) / 128 : 0);
+    p.rs = take(h->h3 && h->cfg.lstm ? (n * g.T + 127) / 128 * 4 : 0);   // one per 32 rows, whole 128-row units
   }
   p.bytes = off;
   return p;
@@ -513,7 +513,7 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
   const bool b16 = h->cfg.precision == CRNN_BF16;
   ConvGemm p{};
   if (!b16 && h->h3 && W3 && a3 && rs && !pmax && C && (K == 256 || K == 512) && N >= 256 && h->lin_gemm) {
-    // f16x3: convert the rows of A (one scale per 128-row block), then the GEMM on the fp16 MFMA
+    // f16x3: convert the rows of A (one scale per 32-row block), then the GEMM on the fp16 MFMA
     ConvGemm q{};
     q.A = a3; q.Wt = (const float*)W3; q.bias = bias; q.C = (float*)C; q.M = M; q.N = N; q.K = K; q.ldc = N;
     q.Hin = q.Win = q.Hout = q.Wout = 1; q.Cin = K; q.ks = 1; q.h3 = 1; q.rs = rs; q.us = us3;

@@ -46,7 +46,7 @@ struct ConvGemm {
   int nbatch;         // 0 or 1 = not batched
   long bsA, bsW, bsC;
   int gn;             // lin_gemm_kernel: column groups of the XCD split (set by launch_lin_gemm)
-  // f16x3 form (lin_gemm_h3_kernel; no arg-max): A and Wt hold (hi, lo) fp16 pairs (crnn_kernels.hip), rs[row / 128] = 1 / the
+  // f16x3 form (lin_gemm_h3_kernel; no arg-max): A and Wt hold (hi, lo) fp16 pairs (crnn_kernels.hip), rs[row / 32] = 1 / the
   // scale of that block of rows (launch_rows_to_f16x3), us = 1 / the weights' scale (to_f16x3_host)
   int h3;
   const float* rs;
@@ -216,7 +216,7 @@ void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t
 bool wino4_out_in_ok(int B, int H, int W, int C, int src);
 void launch_wino4_out_in(const float* M, const float* bias, const float* vs_in, float us, const int32_t* wvalid, float* V,
                          float* vs_out, int B, int H, int W, int C, int act, int src, hipStream_t s);
-// fp32 rows [M][K] (K = 256 or 512; false for any other K) -> f16x3 rows + one unscale factor per block of 128 rows
+// fp32 rows [M][K] (K = 256 or 512; false for any other K) -> f16x3 rows + one unscale factor per block of 32 rows (rs holds 4 per 128-row GEMM unit, whole units)
 bool launch_rows_to_f16x3(const float* A, float* out, float* rs, int M, int K, hipStream_t s);
 // host: rows of K floats -> the f16x3 format with ONE scale for the whole tensor; returns 1 / scale
 float to_f16x3_host(const float* src, size_t n, uint16_t* dst /* 2 n halves */);

@@ -1821,7 +1821,7 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_kernel(const ConvGemm p) {
   __builtin_amdgcn_s_waitcnt(0x0F70);     // no LDS write may be in flight when the block ends
 }
 
-// The same kernel on operands in the f16x3 format (A converted by rows_to_f16x3_kernel with one scale per 128-row block
+// The same kernel on operands in the f16x3 format (A converted by rows_to_f16x3_kernel with one scale per 32-row block
 // = per unit, rs[m-tile] = 1 / scale; W converted at load time with one scale, us = 1 / scale):
 // C = act((hi hi + hi lo + lo hi) rs us + bias).
 __global__ __launch_bounds__(512, 1) void lin_gemm_h3_kernel(const ConvGemm p) {
@@ -1932,9 +1932,9 @@ __global__ __launch_bounds__(512, 1) void lin_gemm_h3_kernel(const ConvGemm p) {
   auto flush = [&]() __attribute__((always_inline)) {
     const int qm = c_u / gw, mt = mb + qm, nt = nb + c_u - qm * gw;
     const int col0 = nt * TBN + wn * 32 + 4 * half;
-    const float r = p.rs[mt] * us;     // one scale per 128-row block = per unit: a scalar load (not in vmcnt)
 #pragma unroll
     for (int m2 = 0; m2 < 2; m2++) {
+      const float r = p.rs[(mt * TBM + wm * 64 + m2 * 32) >> 5] * us;   // one scale per 32 rows: a scalar load (not in vmcnt)
       const int row = mt * TBM + wm * 64 + m2 * 32 + (lane & 31);
 #pragma unroll
       for (int g = 0; g < 4; g++) {
@@ -2514,7 +2514,7 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(const float* __restrict__
     cur ^= 1;
   }
   // padding rows (t >= T_i) of this workgroup's lines and direction: zero, so that what follows (the f16x3 conversion takes
-  // the maximum over blocks of 128 rows) never sees stale workspace contents
+  // the maximum over blocks of 32 rows) never sees stale workspace contents
   for (int ln = 0; ln < LB; ln++) {
     const int bb = b0 + ln;
     if (bb >= B) break;
@@ -3026,15 +3026,18 @@ void launch_argmax_partials(const float* pmax, const int32_t* pidx, int32_t* idx
 // candidates (usually one, then nothing is left to do) are scored exactly: fp32 dot products of the fp32
 // activations and weights, ties to the lowest index.  The decision is therefore made in fp32; bf16 only prunes.
 // ---------------------------------------------------------------------------
-// fp32 rows [M][K] -> the f16x3 format with one scale per block of 128 rows (rs[block] = 1 / scale): the block is a
-// GEMM unit's rows, so the GEMM's epilogue needs one scalar per unit.  One 1024-thread workgroup per block; a thread
-// owns 8 consecutive channels of 128 * K / 8192 rows (all held in registers between the maximum and the conversion).
+// fp32 rows [M][K] -> the f16x3 format with one scale per block of 32 rows (rs[block] = 1 / scale): the rows a wave of
+// the GEMM holds per accumulator, so its epilogue needs two scalars per unit.  (One per 128 rows until round 3: 142
+// workgroups for the 18,176 rows of a 256-line step left 114 CUs idle, 2.6-3.6 TB/s; 568 workgroups now.)  One
+// 256-thread workgroup per block; a thread owns 8 consecutive channels of 32 * K / 2048 rows (all held in registers
+// between the maximum and the conversion).  The grid covers whole 128-row GEMM units: blocks past M write their scale.
+constexpr int F16X3_ROWS = 32;
 template <int K>
-__global__ __launch_bounds__(1024) void rows_to_f16x3_kernel(const float* __restrict__ A, float* __restrict__ out,
-                                                             float* __restrict__ rs, int M) {
-  constexpr int TPR = K / 8, RPI = 1024 / TPR, NIT = 128 / RPI;
-  __shared__ float wmax[16];
-  const int r0 = blockIdx.x * 128 + threadIdx.x / TPR, g8 = threadIdx.x % TPR;
+__global__ __launch_bounds__(256) void rows_to_f16x3_kernel(const float* __restrict__ A, float* __restrict__ out,
+                                                            float* __restrict__ rs, int M) {
+  constexpr int TPR = K / 8, RPI = 256 / TPR, NIT = F16X3_ROWS / RPI;
+  __shared__ float wmax[4];
+  const int r0 = blockIdx.x * F16X3_ROWS + threadIdx.x / TPR, g8 = threadIdx.x % TPR;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f32x4 v[NIT][2];
   float mx = 0.f;
@@ -3052,7 +3055,7 @@ __global__ __launch_bounds__(1024) void rows_to_f16x3_kernel(const float* __rest
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < 16; w++) mx = fmaxf(mx, wmax[w]);
+  for (int w = 0; w < 4; w++) mx = fmaxf(mx, wmax[w]);
   float sc, uns;
   split_scale_from_max(mx, sc, uns);
   if (threadIdx.x == 0) rs[blockIdx.x] = uns;
@@ -3069,9 +3072,9 @@ __global__ __launch_bounds__(1024) void rows_to_f16x3_kernel(const float* __rest
   }
 }
 bool launch_rows_to_f16x3(const float* A, float* out, float* rs, int M, int K, hipStream_t s) {
-  const dim3 g((M + 127) / 128);
-  if (K == 512) hipLaunchKernelGGL((rows_to_f16x3_kernel<512>), g, dim3(1024), 0, s, A, out, rs, M);
-  else if (K == 256) hipLaunchKernelGGL((rows_to_f16x3_kernel<256>), g, dim3(1024), 0, s, A, out, rs, M);
+  const dim3 g((M + 127) / 128 * (128 / F16X3_ROWS));
+  if (K == 512) hipLaunchKernelGGL((rows_to_f16x3_kernel<512>), g, dim3(256), 0, s, A, out, rs, M);
+  else if (K == 256) hipLaunchKernelGGL((rows_to_f16x3_kernel<256>), g, dim3(256), 0, s, A, out, rs, M);
   else return false;
   return true;
 }
