@@ -420,7 +420,7 @@ def main():
         gc.collect()
         model.__del__()          # frees the first handle's streams: both handles' lanes would share the hardware queues
         plain = {}
-        for tag, env in (("conv3_6_gemms_loader_wave_form_of_round_2", {"CRNN_GEMM_PP": "0"}),
+        for tag, env in (("conv3_6_gemms_loader_wave_form_of_round_2", {"CRNN_GEMM_PP": "0", "CRNN_LIN_PP": "0"}),   # (and the plain GEMMs on lin_gemm_h3_kernel)
                          ("classifier_plain_fp32_gemm", {"CRNN_CLS_FILTER": "0"}),
                          ("gemms_on_f32_mfma", {"CRNN_F16X3": "0"}),
                          ("all_on_f32_mfma", {"CRNN_CLS_FILTER": "0", "CRNN_F16X3": "0"})):
@@ -464,7 +464,8 @@ def main():
     # GEMMs, not the direct form), algorithmic bytes].  An f16x3 kernel executes THREE fp16 MFMA products per fp32
     # product: its roofline is the fp16 MFMA's, with 3x those FLOPs.
     wino4_names = [n for n in order if n.endswith("_f4")]
-    wino4pp_names = [n for n in order if n.endswith("_f4pp")]     # the same GEMMs in the ping-pong form (round 3)
+    # the same GEMMs in the ping-pong form (round 3), and the plain GEMMs that run on that kernel (lstm0_ih_pp, ...)
+    wino4pp_names = [n for n in order if n.endswith("_f4pp") or n.endswith("_pp")]
     fused4_names = [n for n in order if n.endswith("_fused4")]      # GEMMs + output transform in one kernel (f16x3 only)
     lin_on = fp32 and os.environ.get("CRNN_LIN_GEMM", "1") != "0"
     lin_names = [n for n in order if lin_on and n in ("lstm0_ih", "lstm1_ih", "emb0", "classifier")]
@@ -492,7 +493,8 @@ def main():
     fams = []
     if wino4pp_names:
         fams.append(family("wino4_gemm_h3_pp_kernel", wino4pp_names,
-                           "the 36 Winograd F(4x4,3x3) component GEMMs of a layer (conv4, conv5: N = 512, K <= 512) as one persistent "
+                           "the 36 Winograd F(4x4,3x3) component GEMMs of a layer (conv4, conv5: N = 512, K <= 512), and the plain "
+                           "GEMMs of the LSTM input projections and the first embedding, each as one persistent "
                            "launch of 256 x 128 units on the fp16 MFMA: operands as (hi, lo) fp16 pairs, 3 MFMA products per fp32 "
                            "product, 64 x 64 wave tiles, two groups of four MFMA waves one slot apart (ping-pong), four loader waves",
                            3, PEAK_BF16_MFMA_TFLOPS))
@@ -565,7 +567,7 @@ def main():
         if n == "cls_filter_bf16":
             mfma_s += cls_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12)
         elif acc[n][1] and not n.startswith("conv0_pool0"):
-            is_h3 = h3 and (n in wino4_names or n in wino4pp_names or n in fused4_names or n in ("lstm0_ih", "lstm1_ih", "emb0"))
+            is_h3 = h3 and (n in wino4_names or n in wino4pp_names or n in fused4_names or n in ("lstm0_ih", "lstm1_ih", "emb0"))   # (wino4pp_names has the *_pp plain GEMMs)
             mfma_s += (3.0 * acc[n][1] / (PEAK_BF16_MFMA_TFLOPS * 1e12)) if is_h3 else acc[n][1] / ((PEAK_F32_MFMA_TFLOPS if fp32 else PEAK_BF16_MFMA_TFLOPS) * 1e12)
     serial_ms = sum(acc[n][0] for n in order)
     peak = dom["peak"]

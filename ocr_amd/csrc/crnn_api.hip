@@ -520,7 +520,15 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
     if (lin_gemm_ok(q) && launch_rows_to_f16x3((const float*)A, a3, rs, M, K, tl_cur->stream)) {
       static const char* cname[3] = {"lstm0_ih_split", "emb0_split", "lstm1_ih_split"};
       kmark(h, cname[name[0] == 'e' ? 1 : (name[4] == '0' ? 0 : 2)], 0, 8.0 * M * K);
-      launch_lin_gemm(q, tl_cur->stream);
+      if (lin_gemm_pp_ok(M, N, K)) {   // whole 256-row units (18,176 rows at 256 lines): the ping-pong GEMM, 8 % quicker
+        Wino4Gemm w{};
+        w.V = a3; w.U = (const float*)W3; w.M = (float*)C; w.ntile_pad = M; w.N = N; w.Cin = K; w.ncomp = 1; w.h3 = 1;
+        w.lin_bias = bias; w.lin_rs = rs; w.lin_us = us3;
+        launch_lin_gemm_pp(w, tl_cur->stream);
+        static const char* ppname[3] = {"lstm0_ih_pp", "emb0_pp", "lstm1_ih_pp"};   // (the launch names tell the kernel)
+        name = ppname[name[0] == 'e' ? 1 : (name[4] == '0' ? 0 : 2)];
+      } else
+        launch_lin_gemm(q, tl_cur->stream);
       kmark(h, name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
       return;
     }

@@ -179,8 +179,16 @@ struct Wino4Gemm {
   int ntile_pad, N, Cin;
   int ncomp;        // number of component GEMMs: 36 (F(4x4,3x3)); 5 for conv6's 1-D F(4,2)
   int h3;           // operands in the f16x3 format (crnn_kernels.hip): V and U hold (hi, lo) fp16 pairs, M leaves scaled
+  // plain-GEMM form of the ping-pong kernel (launch_lin_gemm_pp; ncomp = 1): M = V U^T * lin_rs[row / 32] * lin_us + lin_bias[col]
+  const float* lin_bias;
+  const float* lin_rs;
+  float lin_us;
 };
 bool wino4_gemm_uses_pp(const Wino4Gemm& p);   // this launch runs wino4_gemm_h3_pp_kernel (else the loader-wave / plain form)
+// a plain f16x3 GEMM (A rows from rows_to_f16x3_kernel, W from to_f16x3_host) on wino4_gemm_h3_pp_kernel: rows % 256 == 0,
+// rows >= 1024, N % 128 == 0, K % 64 == 0, K >= 256
+bool lin_gemm_pp_ok(int rows, int N, int K);
+void launch_lin_gemm_pp(const Wino4Gemm& p, hipStream_t s);
 // conv0 + activation + pool0 + conv1's F(4x4) input transform (f16x3 V, per-tile scales) in one kernel; in: [B,32,W] fp32
 void launch_conv0_win4(const float* in, const float* w9x64, const float* bias, float* V, float* vs,
                        const int32_t* w1valid, int B, int W, int act, hipStream_t s, const uint16_t* w3 = nullptr,

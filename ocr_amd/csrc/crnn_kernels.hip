@@ -1281,6 +1281,16 @@ __global__ __launch_bounds__(768, 1) void wino4_gemm_h3_pp_kernel(const Wino4Gem
     unsigned long long ua, ub, pm;
     bases(c_u, ua, ub, pm);
     __attribute__((address_space(1))) float* dst = (__attribute__((address_space(1))) float*)pm + moff;
+    // plain-GEMM form (lstm0_ih, emb0, lstm1_ih): unscale per 32 rows, bias per column (the lane's two columns)
+    float rsc[2] = {1.f, 1.f}, bsv[2] = {0.f, 0.f};
+    if (p.lin_bias) {
+      const int ntu = c_u % ntn, mtu = (c_u / ntn) % ntm;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        rsc[i] = p.lin_rs[mtu * (TBM / 32) + wm * 2 + i] * p.lin_us;
+        bsv[i] = p.lin_bias[ntu * TBN + wn * 64 + i * 32 + (lane & 31)];
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; mt++)
 #pragma unroll
@@ -1290,7 +1300,7 @@ __global__ __launch_bounds__(768, 1) void wino4_gemm_h3_pp_kernel(const Wino4Gem
 #ifdef H3_NOSTORE
           if (acc[mt][nt][r] == 12345.f)
 #endif
-          dst[(mt * 32 + (r & 3) + 8 * (r >> 2)) * p.N + nt * 32] = acc[mt][nt][r];
+          dst[(mt * 32 + (r & 3) + 8 * (r >> 2)) * p.N + nt * 32] = p.lin_bias ? acc[mt][nt][r] * rsc[mt] + bsv[nt] : acc[mt][nt][r];
           acc[mt][nt][r] = 0.f;
         }
     kc = 0;
@@ -2057,6 +2067,17 @@ bool wino4_gemm_uses_pp(const Wino4Gemm& p) {
   const int ppm = ppe ? atoi(ppe) : 1;
   return p.h3 && ppm != 0 && p.Cin >= 256 && p.ntile_pad >= 1024 && p.ntile_pad % 256 == 0 && p.N % 128 == 0 &&
          (ppm == 2 || (p.N >= 512 && p.Cin <= 512));
+}
+
+bool lin_gemm_pp_ok(int rows, int N, int K) {
+  const char* e = getenv("CRNN_LIN_PP");   // 0: the plain GEMMs stay on lin_gemm_h3_kernel (read per launch)
+  if (e && atoi(e) == 0) return false;
+  return rows >= 1024 && rows % 256 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 256 &&
+         (double)rows * K * 4.0 < 2.0e9 && (double)rows * N * 4.0 < 2.0e9;
+}
+void launch_lin_gemm_pp(const Wino4Gemm& p, hipStream_t s) {
+  const int u2 = (p.ntile_pad / 256) * (p.N / 128);
+  hipLaunchKernelGGL(wino4_gemm_h3_pp_kernel, dim3(u2 < persistent_blocks() ? 8 * ((u2 + 7) / 8) : persistent_blocks()), dim3(768), 0, s, p);
 }
 
 void launch_wino4_gemm(const Wino4Gemm& p, hipStream_t s) {

@@ -167,3 +167,39 @@ np.savez(sys.argv[1], s1=s1, lg=lg)
     clear = (top2[..., 1] - top2[..., 0]) > 2e-3          # rows whose winner is not a near-tie
     assert clear.mean() > 0.99
     assert np.array_equal(a["lg"].argmax(-1)[clear], b["lg"].argmax(-1)[clear])
+
+
+def test_plain_gemms_on_the_ping_pong_kernel(zh):
+    """From whole 256-row units (n T a multiple of 256: 256 lines of width 280) the LSTM input projections and the first
+    embedding run on wino4_gemm_h3_pp_kernel with a scale-and-bias epilogue (CRNN_LIN_PP, read per call).  Same operands,
+    same products, a different summation order inside the MFMA chains: stages 7 (embedding), 9 and the logits agree
+    with lin_gemm_h3_kernel's to fp32 rounding / the usual amplification."""
+    rs = np.random.RandomState(5)
+    x = (rs.randint(0, 256, size=(256, 32, 280)).astype(np.float32) / 255.0 - 0.5) / 0.5
+    def both(stage):
+        os.environ["CRNN_LIN_PP"] = "0"
+        try:
+            a = zh.debug_stage(x, stage)
+        finally:
+            os.environ.pop("CRNN_LIN_PP", None)
+        return a, zh.debug_stage(x, stage)
+    a, b = both(7)
+    assert np.abs(a).max() > 0 and np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
+    a, b = both(10)
+    assert np.abs(a - b).max() < 1e-3
+    top2 = np.sort(a, axis=-1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 2e-3
+    assert clear.mean() > 0.99 and np.array_equal(a.argmax(-1)[clear], b.argmax(-1)[clear])
+    import torch
+    dev = torch.device("cuda", 0)
+    lines = torch.randint(0, 256, (256, 32, 280), dtype=torch.uint8, device=dev)
+    lab = torch.zeros((256, 71), dtype=torch.int32, device=dev)
+    ln = torch.zeros((256,), dtype=torch.int32, device=dev)
+    zh.set_profiling(True)
+    try:
+        zh.forward_device(lines.data_ptr(), 256, 280, lab.data_ptr(), ln.data_ptr())
+        zh.synchronize()
+        names = [k[0] for k in zh.kernel_times()]
+    finally:
+        zh.set_profiling(False)
+    assert "lstm0_ih_pp" in names and "emb0_pp" in names and "lstm1_ih_pp" in names

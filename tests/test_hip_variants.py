@@ -57,6 +57,7 @@ VARIANTS = [
     ({"CRNN_GEMM_PP": "0"}, 1),                               # conv4 / conv5 GEMMs on the loader-wave form instead of the ping-pong form
     ({"CRNN_GEMM_PP": "2", "CRNN_WINO4_FUSE": "0"}, 2),       # the ping-pong form on every layer it can take
     ({"CRNN_EQUALIZE": "0"}, 1),                              # no load-time channel equalisation
+    ({"CRNN_LIN_PP": "0"}, 1),                                # LSTM input projections / first embedding on lin_gemm_h3_kernel at every size
     ({"CRNN_CONV0_MFMA": "0"}, 1),                            # conv0 (inside the fused conv0 / conv1-input kernel) as scalar fp32 FMAs
 ]
 
@@ -66,7 +67,7 @@ VARIANTS = [
 def test_variant_strings_match_reference_goldens(env, lanes, golden):
     _, M = golden
     e = dict(os.environ)
-    for k in ("CRNN_WINOGRAD_F4", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_POOL21", "CRNN_WINO6", "CRNN_CLS_FILTER", "CRNN_F16X3", "CRNN_REC_H3", "CRNN_LSTM_SPLIT", "CRNN_CLS_F16", "CRNN_WINO4_FUSE", "CRNN_CONV0_FUSED", "CRNN_GEMM16_DMA", "CRNN_REC_RES", "CRNN_GEMM_PP", "CRNN_EQUALIZE", "CRNN_CONV0_MFMA", "CRNN_WINO4_CHAIN"):
+    for k in ("CRNN_WINOGRAD_F4", "CRNN_WINO4_MIN_N", "CRNN_LIN_GEMM", "CRNN_WINO4_POOL21", "CRNN_WINO6", "CRNN_CLS_FILTER", "CRNN_F16X3", "CRNN_REC_H3", "CRNN_LSTM_SPLIT", "CRNN_CLS_F16", "CRNN_WINO4_FUSE", "CRNN_CONV0_FUSED", "CRNN_GEMM16_DMA", "CRNN_REC_RES", "CRNN_GEMM_PP", "CRNN_EQUALIZE", "CRNN_CONV0_MFMA", "CRNN_WINO4_CHAIN", "CRNN_LIN_PP"):
         e.pop(k, None)
     e.update(env)
     code = CHILD % (ROOT, os.path.join(ROOT, "tests", "golden", "crnn_golden.npz"),
