@@ -191,7 +191,7 @@ def lines_job(args, model, dev, rank, world, dist):
                                       "the host (timed)" % (N, args.seed, world, args.precision),
                           "lines": N, "batch": BATCH, "width": WIDTH, "nclass": NCLASS, "lanes_per_gpu": NL,
                           "buckets_rank0": nb, "sharding": "independent lines, one replica per GPU, no collective",
-                          "gpu_max_hw_queues": _hw_queues()},
+                          "gpu_max_hw_queues": _hw_queues(), "split_timeouts_rank0": model.split_timeouts()},
                "elapsed_s": round(elapsed, 3), "decoded_chars": chars, "strings_sha256": digest,
                "lines_per_rank": [len(p) for p in parts]}
         print(json.dumps(out, ensure_ascii=False))
@@ -361,6 +361,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    split_tmo = model.split_timeouts()   # give-ups of the hidden-split recurrence so far (warm-up + timed region): 0 expected
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -446,7 +447,6 @@ def main():
             model2.__del__()
             del model2
 
-    split_tmo = model.split_timeouts() if plain is None else None   # (the first handle is gone when the alternatives ran)
     run = None          # same order at every exit: pinned buffers (held by the closure) go before the handle's streams
     gc.collect()
     if rank != 0:
