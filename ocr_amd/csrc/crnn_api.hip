@@ -509,7 +509,8 @@ static bool use_lin_gemm(const crnn_handle* h, const ConvGemm& p) {
 // out_bf16 only matters on the bf16 path (which GEMM outputs feed another GEMM)
 void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, const uint16_t* Wt16,
           const float* bias, void* C, int M, int N, int K, bool out_bf16, float* pmax = nullptr,
-          int32_t* pidx = nullptr, const uint16_t* W3 = nullptr, float us3 = 1.f, float* a3 = nullptr, float* rs = nullptr) {
+          int32_t* pidx = nullptr, const uint16_t* W3 = nullptr, float us3 = 1.f, float* a3 = nullptr, float* rs = nullptr,
+          bool a3_ready = false) {
   const bool b16 = h->cfg.precision == CRNN_BF16;
   ConvGemm p{};
   if (!b16 && h->h3 && W3 && a3 && rs && !pmax && C && (K == 256 || K == 512) && N >= 256 && h->lin_gemm) {
@@ -517,9 +518,9 @@ void gemm(crnn_handle* h, const char* name, const void* A, const float* Wt, cons
     ConvGemm q{};
     q.A = a3; q.Wt = (const float*)W3; q.bias = bias; q.C = (float*)C; q.M = M; q.N = N; q.K = K; q.ldc = N;
     q.Hin = q.Win = q.Hout = q.Wout = 1; q.Cin = K; q.ks = 1; q.h3 = 1; q.rs = rs; q.us = us3;
-    if (lin_gemm_ok(q) && launch_rows_to_f16x3((const float*)A, a3, rs, M, K, tl_cur->stream)) {
+    if (lin_gemm_ok(q) && (a3_ready || launch_rows_to_f16x3((const float*)A, a3, rs, M, K, tl_cur->stream))) {
       static const char* cname[3] = {"lstm0_ih_split", "emb0_split", "lstm1_ih_split"};
-      kmark(h, cname[name[0] == 'e' ? 1 : (name[4] == '0' ? 0 : 2)], 0, 8.0 * M * K);
+      if (!a3_ready) kmark(h, cname[name[0] == 'e' ? 1 : (name[4] == '0' ? 0 : 2)], 0, 8.0 * M * K);
       if (lin_gemm_pp_ok(M, N, K)) {   // whole 256-row units (18,176 rows at 256 lines): the ping-pong GEMM, 8 % quicker
         Wino4Gemm w{};
         w.V = a3; w.U = (const float*)W3; w.M = (float*)C; w.ntile_pad = M; w.N = N; w.Cin = K; w.ncomp = 1; w.h3 = 1;
@@ -563,7 +564,7 @@ static bool conv_on_wino4_h3(const crnn_handle* h, int layer, int n, int Cin) {
 int conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvalid, int n, int Hin, int Win,
          int Cin, int Hout, int Wout, float* wino_v = nullptr, float* wino_m = nullptr, float* pool_out = nullptr,
          float* pool21_out = nullptr, float* vs = nullptr, bool v_ready = false, int chain_src = -1,
-         float* vs_next = nullptr) {
+         float* vs_next = nullptr, float* split_a3 = nullptr, float* split_rs = nullptr, bool split_only = false) {
   static const char* names[7] = {"conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6"};
   const bool b16 = h->cfg.precision == CRNN_BF16;
   // (with f16x3 weights only the split form of U exists: a shape that form does not take falls through to the direct conv)
@@ -652,6 +653,13 @@ int conv(crnn_handle* h, int layer, const void* A, void* C, const int32_t* wvali
     w.Cin = 2 * Cin; w.ncomp = 5; w.h3 = h3;
     launch_wino4_gemm(w, s);
     kmark(h, wino4_gemm_uses_pp(w) ? "conv6_f4pp" : "conv6_f4", 2.0 * 5 * tiles * Co * 2 * Cin, 4.0 * 5 * ((double)tiles * 2 * Cin + (double)Co * 2 * Cin + (double)tiles * Co));
+    if (h3 && split_a3 && split_rs && Co == 512) {
+      // conv6's output transform writes the first LSTM projection's f16x3 operand itself (split_only: and no fp32 rows)
+      launch_wino42_out_split(wino_m, h->d_conv_b[6], split_only ? nullptr : (float*)C, split_a3, split_rs, n, Wout,
+                              h->cfg.leaky_relu ? 2 : 1, s, vs, h->wino4_us[6]);
+      kmark(h, "conv6_wout4_split", 0, 4.0 * (5.0 * tiles * Co + (split_only ? 1.0 : 2.0) * n * Wout * Co));
+      return 3;
+    }
     launch_wino42_out(wino_m, h->d_conv_b[6], (float*)C, n, Wout, Co, h->cfg.leaky_relu ? 2 : 1, s, h3 ? vs : nullptr,
                       h->wino4_us[6]);
     kmark(h, "conv6_wout4", 0, 4.0 * (5.0 * tiles * Co + (double)n * Wout * Co));
@@ -741,7 +749,19 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
     else launch_pool_2x2s21p01(p.c5, p.p3, n, 4, g.W3, 512, s);
     kmark(h, "pool3", 0, es * (dn * 4 * g.W3 * 512 + dn * 2 * g.W4 * 512));
   }
-  conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T, p.wv, p.wm, nullptr, nullptr, vs_a, r5 == 2);
+  // conv6's output transform can write the first LSTM projection's f16x3 operand itself (CRNN_CONV6_SPLIT=0: separate
+  // kernels); the fp32 sequence tensor is then written only for a debug request (stage 6)
+  bool seq_split = false;
+  {
+    const char* c6e = getenv("CRNN_CONV6_SPLIT");   // (read per call)
+    const bool c6s = !(c6e && atoi(c6e) == 0);
+    ConvGemm q{};
+    q.M = n * g.T; q.N = 2048; q.K = 512; q.ks = 1;
+    const bool lin_h3 = !b16 && h->h3 && h->cfg.lstm && h->d_wih_h3[0] && p.a3 && p.rs && h->lin_gemm && lin_gemm_ok(q);
+    const int r6 = conv(h, 6, p.p3, p.seq, nullptr, n, 2, g.W4, 512, 1, g.T, p.wv, p.wm, nullptr, nullptr, vs_a, r5 == 2, -1,
+                        nullptr, c6s && lin_h3 ? p.a3 : nullptr, p.rs, st_want != 6);
+    seq_split = r6 == 3;
+  }
   HIPCHK(h, hipEventRecord(tl_cur->ev[2], s));
   const int M = n * g.T;
   const double recflop = 2.0 * M * 2 * 1024 * 256;
@@ -809,7 +829,7 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
   };
   if (h->cfg.lstm) {
     gemm(h, "lstm0_ih", p.seq, h->d_wih[0], h->db_wih[0], h->d_bih[0], p.xp, M, 2048, 512, false, nullptr, nullptr,
-         h->d_wih_h3[0], h->wih_us[0], p.a3, p.rs);
+         h->d_wih_h3[0], h->wih_us[0], p.a3, p.rs, seq_split);
     rec(0, p.rec0);
     gemm(h, "emb0", p.rec0, h->d_emb_w[0], h->db_emb_w[0], h->d_emb_b[0], p.mid, M, 256, 512, true, nullptr, nullptr,
          h->d_emb0_h3, h->emb0_us, p.a3, p.rs);

@@ -224,6 +224,11 @@ void launch_wino4_out(const float* M, const float* bias, float* y, const int32_t
 bool wino4_out_in_ok(int B, int H, int W, int C, int src);
 void launch_wino4_out_in(const float* M, const float* bias, const float* vs_in, float us, const int32_t* wvalid, float* V,
                          float* vs_out, int B, int H, int W, int C, int act, int src, hipStream_t s);
+constexpr int F16X3_ROWS = 32;   // rows per scale of a plain GEMM's f16x3 A operand
+// conv6's output transform writing the f16x3 rows (and scales) of the first LSTM projection's A operand directly; y (the
+// fp32 rows) only if not null.  Cout = 512.
+void launch_wino42_out_split(const float* M, const float* bias, float* y, float* a3, float* rs, int B, int T, int act,
+                             hipStream_t s, const float* vs, float us);
 // fp32 rows [M][K] (K = 256 or 512; false for any other K) -> f16x3 rows + one unscale factor per block of 32 rows (rs holds 4 per 128-row GEMM unit, whole units)
 bool launch_rows_to_f16x3(const float* A, float* out, float* rs, int M, int K, hipStream_t s);
 // host: rows of K floats -> the f16x3 format with ONE scale for the whole tensor; returns 1 / scale

@@ -2249,6 +2249,78 @@ __global__ __launch_bounds__(256) void wino42_out_kernel(const float* __restrict
   }
 }
 
+// conv6's output transform AND the f16x3 conversion of its rows (the A operand of the first LSTM input projection) in
+// one kernel: the fp32 sequence tensor is written only on request (y), and rows_to_f16x3_kernel's launch and its read
+// of that tensor go away.  Workgroup = one 32-row block of the GEMM operand (its scale is the block's maximum):
+// 128 threads x 4 channels for each of two rows per pass, 16 passes; a thread computes the one output column of the
+// tile its row needs (the tile's five products are read by the four rows that share it: L1 hits).  The same
+// expressions on the same values as wino42_out_kernel + rows_to_f16x3_kernel<512>: identical bits (tests/test_hip_chain.py).
+__global__ __launch_bounds__(256) void wino42_out_split_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
+                                                               float* __restrict__ y, float* __restrict__ a3,
+                                                               float* __restrict__ rs, int B, int T, int act,
+                                                               long ntile_pad, const float* __restrict__ vs, float us) {
+  constexpr int Co = 512;
+  __shared__ float wmax[4];
+  const int c4 = threadIdx.x & 127, rsub = threadIdx.x >> 7, tw = (T + 3) >> 2;
+  const long rows = (long)B * T, r0 = (long)blockIdx.x * F16X3_ROWS;
+  const f32x4 bs = *(const f32x4*)(bias + c4 * 4);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 val[F16X3_ROWS / 2];
+  float mx = 0.f;
+#pragma unroll
+  for (int it = 0; it < F16X3_ROWS / 2; it++) {
+    const long row = r0 + it * 2 + rsub;
+    val[it] = z;
+    if (row < rows) {
+      const int b = (int)(row / T), xx = (int)(row - (long)b * T), j = xx & 3;   // (uniform over a wave)
+      const long t = (long)b * tw + (xx >> 2);
+      f32x4 m[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) m[k] = *(const f32x4*)(Mo + ((long)k * ntile_pad + t) * Co + c4 * 4);
+      const float r = vs[t] * us;
+      const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2];
+      f32x4 o;
+      if (j == 0) o = m[0] + s12 + m[3];
+      else if (j == 1) o = d12 + 2.f * m[3];
+      else if (j == 2) o = s12 + 4.f * m[3];
+      else o = d12 + 8.f * m[3] + m[4];
+      f32x4 v = o * r + bs;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        float e = v[c];
+        if (act == 1) e = e > 0.f ? e : 0.f;
+        else if (act == 2) e = e > 0.f ? e : 0.2f * e;
+        v[c] = e;
+        mx = fmaxf(mx, __builtin_fabsf(e));
+      }
+      val[it] = v;
+      if (y) *(f32x4*)(y + row * Co + c4 * 4) = v;
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  float sc, uns;
+  split_scale_from_max(mx, sc, uns);
+  if (threadIdx.x == 0) rs[blockIdx.x] = uns;
+#pragma unroll
+  for (int it = 0; it < F16X3_ROWS / 2; it++) {
+    const long row = r0 + it * 2 + rsub;
+    if (row >= rows) continue;
+    uint2 hi, lo;
+    split4(val[it], sc, hi, lo);
+    *(i32x4*)(a3 + row * Co + (c4 >> 1) * 8 + (c4 & 1) * 4) = split_pair_chunk(c4, hi, lo);
+  }
+}
+void launch_wino42_out_split(const float* M, const float* bias, float* y, float* a3, float* rs, int B, int T, int act,
+                             hipStream_t s, const float* vs, float us) {
+  const long tiles = (long)B * ((T + 3) / 4), rows = (long)B * T;
+  const unsigned g = (unsigned)((rows + 127) / 128 * (128 / F16X3_ROWS));   // whole 128-row GEMM units, as rows_to_f16x3_kernel
+  hipLaunchKernelGGL(wino42_out_split_kernel, dim3(g), dim3(256), 0, s, M, bias, y, a3, rs, B, T, act, wino4_pad(tiles), vs, us);
+}
+
 void launch_wino42_in(const float* x, float* V, int B, int W, int C, hipStream_t s, float* vs) {
   const long tiles = (long)B * ((W - 1 + 3) / 4);
   if (vs && C == 512)
@@ -3052,7 +3124,6 @@ void launch_argmax_partials(const float* pmax, const int32_t* pidx, int32_t* idx
 // workgroups for the 18,176 rows of a 256-line step left 114 CUs idle, 2.6-3.6 TB/s; 568 workgroups now.)  One
 // 256-thread workgroup per block; a thread owns 8 consecutive channels of 32 * K / 2048 rows (all held in registers
 // between the maximum and the conversion).  The grid covers whole 128-row GEMM units: blocks past M write their scale.
-constexpr int F16X3_ROWS = 32;
 template <int K>
 __global__ __launch_bounds__(256) void rows_to_f16x3_kernel(const float* __restrict__ A, float* __restrict__ out,
                                                             float* __restrict__ rs, int M) {

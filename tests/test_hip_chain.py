@@ -203,3 +203,29 @@ def test_plain_gemms_on_the_ping_pong_kernel(zh):
     finally:
         zh.set_profiling(False)
     assert "lstm0_ih_pp" in names and "emb0_pp" in names and "lstm1_ih_pp" in names
+
+
+@pytest.mark.parametrize("n,w,ragged", [(256, 280, False), (100, 280, True), (7, 64, True), (130, 200, True)])
+def test_conv6_output_transform_writing_the_lstm_operand(zh, n, w, ragged):
+    """conv6's output transform writes the f16x3 rows and 32-row scales of the first LSTM projection itself
+    (wino42_out_split_kernel; CRNN_CONV6_SPLIT=0: wino42_out_kernel + rows_to_f16x3_kernel).  Same expressions on the
+    same values: the embedding (stage 7), the last recurrence (9) and the logits are bit-identical, and a request for
+    the fp32 sequence tensor (stage 6) still gets it."""
+    rs = np.random.RandomState(n * 3 + w)
+    x = (rs.randint(0, 256, size=(n, 32, w)).astype(np.float32) / 255.0 - 0.5) / 0.5
+    widths = None
+    if ragged:
+        widths = rs.randint(max(8, w // 3), w + 1, size=n).astype(np.int32)
+        widths[0] = w
+        for i in range(n):
+            x[i, :, widths[i]:] = 0.0
+    def off(stage):
+        os.environ["CRNN_CONV6_SPLIT"] = "0"
+        try:
+            return zh.debug_stage(x, stage, widths)
+        finally:
+            os.environ.pop("CRNN_CONV6_SPLIT", None)
+    for stage in (6, 7, 9, 10):
+        a, b = off(stage), zh.debug_stage(x, stage, widths)
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        assert np.array_equal(a, b), "stage %d" % stage
