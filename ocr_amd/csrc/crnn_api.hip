@@ -793,7 +793,12 @@ int run_network(crnn_handle* h, const Geo& g, const Plan& p, const int32_t* widt
       if (ch.pid != getpid()) { ch.ev = nullptr; ch.pid = getpid(); }     // a forked child starts its own chain
       if (!ch.ev) (void)hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming);
       if (ch.ev) (void)hipStreamWaitEvent(s, ch.ev, 0);
-      launch_lstm_rec_split_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], d_sync, s);
+      // two row tiles (32 lines) per workgroup where the recurrence shares the chip with another batch's kernels (the
+      // asynchronous path, from 128 lines): half the workgroups, steps a little longer (the kernel).  CRNN_SPLIT_NT=1 / 2
+      // forces one form (read per call)
+      const char* nte = getenv("CRNN_SPLIT_NT");
+      const int nt = nte && atoi(nte) > 0 ? (atoi(nte) >= 2 ? 2 : 1) : (gated && n >= 128 ? 2 : 1);
+      launch_lstm_rec_split_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], d_sync, s, nt);
       if (ch.ev) (void)hipEventRecord(ch.ev, s);
       if (gated) launch_lstm_rec_h3(p.xp, h->d_whh3[l], out, tlen, n, g.T, h->whh3_unscale[l], s, d_sync);
     }

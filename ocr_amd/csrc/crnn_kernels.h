@@ -256,7 +256,7 @@ void launch_lstm_rec(const float* xp, const float* whh_packed, float* rec, const
 // the same on the fp16 MFMA in the f16x3 form (weights from pack_whh_h3, unscale as for launch_lstm_rec_h3): bit-identical to
 // lstm_rec_h3_kernel
 void launch_lstm_rec_split_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T,
-                              float unscale, unsigned* tmo, hipStream_t s);
+                              float unscale, unsigned* tmo, hipStream_t s, int nt = 1);
 // f16x3 form of the recurrence (crnn_kernels.hip): whh3 from pack_whh_h3 (2 * 1024 * 256 * 2 halves), unscale its return value
 // empty launches, one per translation unit of kernels (device set-up: code objects loaded, stream queues created)
 void launch_warm_main(hipStream_t s);

@@ -2874,6 +2874,21 @@ float pack_whh_h3(const float* whh_fwd, const float* whh_rev, uint16_t* packed /
 // h value the fill pattern itself (a NaN with all bits set) ends the same way.
 // ---------------------------------------------------------------------------
 constexpr unsigned SPLIT_MAX_SPINS = 1u << 16;
+// tools/rec_bench.hip builds this file with -DREC_PROF: workgroup (0, 0)'s thread 0 sums the 100 MHz wall clock over the
+// phases of its steps into tmo[16 ..] (not in the product build)
+#ifdef REC_PROF
+#define REC_PROF_DECL long long rp_t = 0, rp_sum[6] = {0, 0, 0, 0, 0, 0}; const bool rp_on = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0
+#define REC_STAMP0() do { if (rp_on) rp_t = wall_clock64(); } while (0)
+#define REC_STAMP(i) do { if (rp_on) { const long long n_ = wall_clock64(); rp_sum[i] += n_ - rp_t; rp_t = n_; } } while (0)
+#define REC_COUNT(i, n) do { if (rp_on) rp_sum[i] += (n); } while (0)
+#define REC_PROF_OUT() do { if (rp_on) for (int i_ = 0; i_ < 6; i_++) tmo[16 + i_] = (unsigned)rp_sum[i_]; } while (0)
+#else
+#define REC_PROF_DECL
+#define REC_STAMP0()
+#define REC_STAMP(i)
+#define REC_COUNT(i, n)
+#define REC_PROF_OUT()
+#endif
 typedef __attribute__((address_space(1))) unsigned gu32_t;
 
 
@@ -2940,7 +2955,9 @@ __global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __r
   // where this lane's four units go in a line's split image
   const int myu = part * 64 + wave * 16 + q * 4;
   const int my_lds = bl * HLS + ((myu >> 3) & 3) * 256 + (myu >> 5) * 32 + (myu & 7) * 2;
+  REC_PROF_DECL;
   for (int s = 0; s < Tmax; s++) {
+    REC_STAMP0();
     const bool active = s < Ti;
     const int t = active ? (dir ? (Ti - 1 - s) : s) : 0;
     const size_t rowi = (size_t)(b < B ? b : 0) * T + t;
@@ -2966,6 +2983,7 @@ __global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __r
       for (int g = 0; g < 4; g++)
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[g][ks][0]), hh, acc[g], 0, 0, 0);
     }
+    REC_STAMP(0);
     f32x4 hv4;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -2989,6 +3007,7 @@ __global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __r
     if (active)   // write-through store: the output row AND the hand-off to the other three workgroups
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv4), rec_rsrc,
                                              (unsigned)((rowi * 512 + dir * 256 + myu) * 4), 0, 16);
+    REC_STAMP(2);
     // the other parts' h of this step: the protocol described above (the fill pattern is the arrival flag)
     {
       i32x4 v[3];
@@ -3019,6 +3038,8 @@ __global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __r
         __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_fail = 1;
       }
+      REC_COUNT(4, spins);
+      REC_STAMP(1);
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         unsigned char* dst = hs + (cur ^ 1) * LB * HLS + xl_lds[i];
@@ -3030,11 +3051,14 @@ __global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __r
         *(uint2*)(dst + 16) = lo;
       }
     }
+    REC_STAMP(3);
     __syncthreads();
     if (s_fail) return;     // uniform: everybody leaves; the host repeats the batch with the one-workgroup kernel
     __syncthreads();
+    REC_STAMP(5);
     cur ^= 1;
   }
+  REC_PROF_OUT();
   // padding rows (t >= T_i) of this workgroup's lines, direction and 64 units: zero instead of the fill pattern
   for (int ln = 0; ln < LB; ln++) {
     const int bb = b0 + ln;
@@ -3045,13 +3069,261 @@ __global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------
+// Two-tile form of the hidden-split recurrence (round 3, last session): what a recurrence costs in the PIPELINE is what it
+// keeps the other batch's kernels from using -- workgroups x time, every workgroup a whole CU (its waves fill the register
+// files) -- and a step of the kernel above is latency (hand-off, loads, barriers), not work.  Here a group of four workgroups
+// owns 32 lines as two row tiles of 16 and alternates between them: while the h of tile A's step travels to the other
+// three parts, the workgroup computes tile B's step, and the other way round.  A half-step: request the tile's input
+// projections; the tile's 96 MFMAs per wave, the polling loads for the OTHER tile's chunks (stored by the other parts in
+// the half-step before) issued PK k-steps in; check them (they have had the rest of the MFMAs to arrive; the poll loop of
+// the kernel above only runs if one has not), split them into the other tile's next h image; gates, own units into this
+// tile's next image and write-through to the output row; ONE barrier (the give-up flag alternates with the half-steps).
+// Half as many workgroups as the kernel above, and a step of 32 lines takes about as long as its step of 16.
+// Same weights, same MFMA sequence per accumulator, same gate math: bit-identical to both other forms
+// (tests/test_hip_scale.py).  Same protocol (fill pattern = arrival flag, bounded polls, *tmo).
+// ---------------------------------------------------------------------------
+template <int PK>
+__global__ __launch_bounds__(256) void lstm_rec_split2_h3_kernel(const float* __restrict__ xp,
+                                                                 const uint4* __restrict__ whh3, float* rec,
+                                                                 const int32_t* __restrict__ tlen, int B, int T,
+                                                                 float unscale, unsigned* tmo) {
+  constexpr int LBN = 2 * LB;
+  __shared__ __attribute__((aligned(16))) unsigned char hs[2 * LBN * HLS];   // [image][tile][line]
+  __shared__ int s_fail[2];
+  const int dir = blockIdx.y, grp = blockIdx.x >> 2, part = blockIdx.x & 3, b0 = grp * LBN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
+  int Ti[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int b = b0 + j * LB + bl;
+    Ti[j] = (b < B) ? (tlen ? tlen[b] : T) : 0;
+  }
+  int Tmax = 0;
+  for (int j = 0; j < LBN; j++) {
+    const int bb = b0 + j;
+    const int tj = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
+    Tmax = tj > Tmax ? tj : Tmax;
+  }
+  for (int i = tid; i < 2 * LBN * HLS / 4; i += 256) ((unsigned*)hs)[i] = 0u;
+  if (tid < 2) s_fail[tid] = 0;
+  // exchange loads of ONE tile: 3 other parts x 16 lines x 16 chunks of 4 units = 768 float4, 3 per thread
+  int xl_line[3], xl_unit[3], xl_lds[3], xl_T[2][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int e = i * 256 + tid;            // 0..767
+    const int op = e >> 8;                  // which of the 3 other parts
+    const int p2 = op + (op >= part ? 1 : 0);
+    xl_line[i] = (e >> 4) & 15;
+    xl_unit[i] = p2 * 64 + (e & 15) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int bb = b0 + j * LB + xl_line[i];
+      xl_T[j][i] = (bb < B) ? (tlen ? tlen[bb] : T) : 0;
+    }
+    const int k = xl_unit[i];               // units k .. k + 3: block [k / 8 mod 4][k / 32], halves (k & 7) .. + 3
+    xl_lds[i] = xl_line[i] * HLS + ((k >> 3) & 3) * 256 + (k >> 5) * 32 + (k & 7) * 2;
+  }
+  const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, 0x7FFFFFFF, 0x00020000);
+  float c[2][4], h[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { c[j][r] = 0.f; h[j][r] = 0.f; }
+  uint4 w[4][8][2];   // the wave's weights, resident (lstm_rec_split_h3_kernel)
+  {
+    const uint4* wp = whh3 + ((size_t)(dir * 4 + part) * 8 * 16 * 2) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        w[g][ks][0] = wp[(size_t)((ks * 16 + g * 4 + wave) * 2) * 64];
+        w[g][ks][1] = wp[(size_t)((ks * 16 + g * 4 + wave) * 2 + 1) * 64];
+      }
+  }
+  __syncthreads();
+  int cur[2] = {0, 0};   // the complete h image of each tile
+  REC_PROF_DECL;
+  const int myu = part * 64 + wave * 16 + q * 4;
+  const int my_lds = bl * HLS + ((myu >> 3) & 3) * 256 + (myu >> 5) * 32 + (myu & 7) * 2;
+  // The input projections of a half-step are requested during the half-step before, right after that one's wait for its
+  // polling loads (a wait for loads is a wait for ALL loads issued before it, so anything requested earlier would be
+  // waited for there): they have the rest of that half-step and this one's MFMAs to arrive.  Unconditional loads (a line
+  // past its end reads its row 0 and ignores it).
+  f32x4 xgs[2][4];
+  auto request_xg = [&](int tile, int step) __attribute__((always_inline)) {
+    const int b = b0 + tile * LB + bl;
+    const int t = step < Ti[tile] ? (dir ? (Ti[tile] - 1 - step) : step) : 0;
+    const float* xrow = xp + ((size_t)(b < B ? b : 0) * T + t) * 2048 + dir * 1024 + part * 64 + wave * 16 + q * 4;
+#pragma unroll
+    for (int g = 0; g < 4; g++) xgs[tile][g] = *(const f32x4*)(xrow + g * 256);
+    asm volatile("" ::: "memory");
+  };
+  request_xg(0, 0);
+  for (int s = 0; s < Tmax; s++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int o = 1 - j;
+      REC_STAMP0();
+      // ---- this tile's step
+      const int b = b0 + j * LB + bl;
+      const bool active = s < Ti[j];
+      const int t = active ? (dir ? (Ti[j] - 1 - s) : s) : 0;
+      const size_t rowi = (size_t)(b < B ? b : 0) * T + t;
+      f32x4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // ---- the other tile's hand-off of the half-step before: its step so (tile 1's previous step when this is tile 0);
+      // needed only if that tile has another step to compute
+      const int so = j == 0 ? s - 1 : s;
+      const bool xch = so >= 0 && so + 1 < Tmax;       // (uniform)
+      i32x4 v[3];
+      bool act[3], pend[3];
+      unsigned ro[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int Tl = xl_T[o][i], ln = xl_line[i];
+        act[i] = xch && so < Tl;
+        const int tl = dir ? (Tl - 1 - so) : so;
+        const int bb = b0 + o * LB + ln;
+        // (a chunk nobody needs -- a line past its end, a padding line of the group -- is loaded all the same, from a valid
+        // row: a load under a condition would be waited for at the end of its branch, one round trip after the other)
+        ro[i] = (unsigned)((((size_t)(bb < B ? bb : 0) * T + (act[i] ? tl : 0)) * 512 + dir * 256 + xl_unit[i]) * 4);
+        pend[i] = act[i];
+      }
+      const unsigned char* hrow = hs + (cur[j] * LBN + j * LB) * HLS + bl * HLS + q * 256;
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        if (ks == PK) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, ro[i], 0, 16);
+          asm volatile("" ::: "memory");   // (a pure read to the compiler, which would sink it to its first use)
+        }
+        const f16x8r hh = *(const f16x8r*)(hrow + ks * 32), hl = *(const f16x8r*)(hrow + ks * 32 + 16);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[g][ks][1]), hh, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[g][ks][0]), hl, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8r, w[g][ks][0]), hh, acc[g], 0, 0, 0);
+      }
+      if (PK >= 8) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, ro[i], 0, 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      REC_STAMP(0);
+      // ---- the other tile's chunks: arrived?  (the fill pattern is the arrival flag; lstm_rec_split_h3_kernel's loop otherwise)
+      if (xch) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          if (pend[i]) pend[i] = v[i][0] == -1 || v[i][1] == -1 || v[i][2] == -1 || v[i][3] == -1;
+          any = any || pend[i];
+        }
+        unsigned spins = 0;
+        bool fail = false;
+        while (any) {
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+            if (pend[i]) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, ro[i], 0, 16);
+          any = false;
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            if (pend[i]) pend[i] = v[i][0] == -1 || v[i][1] == -1 || v[i][2] == -1 || v[i][3] == -1;
+            any = any || pend[i];
+          }
+          if (++spins > SPLIT_MAX_SPINS) { fail = true; break; }
+          if ((spins & 255u) == 0 &&
+              __hip_atomic_load((gu32_t*)tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = true; break; }
+        }
+        if (fail) {
+          __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_fail[j] = 1;
+        }
+        REC_COUNT(4, spins);
+        REC_STAMP(1);
+      }
+      // ---- the next half-step's input projections (tile o: step s when this is tile 0, else s + 1; past the end: any row)
+      request_xg(o, j == 0 ? s : (s + 1 < Tmax ? s + 1 : s));
+      if (xch) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          unsigned char* dst = hs + ((cur[o] ^ 1) * LBN + o * LB) * HLS + xl_lds[i];
+          const unsigned char* old = hs + (cur[o] * LBN + o * LB) * HLS + xl_lds[i];
+          uint2 hi, lo;
+          if (act[i]) split4(__builtin_bit_cast(f32x4, v[i]), 16384.f, hi, lo);
+          else { hi = *(const uint2*)old; lo = *(const uint2*)(old + 16); }
+          *(uint2*)dst = hi;
+          *(uint2*)(dst + 16) = lo;
+        }
+      }
+      REC_STAMP(2);
+      // ---- this tile's gates
+      f32x4 hv4;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (active) {
+          const float ig = sigmoidf_(acc[0][r] * unscale + xgs[j][0][r]);
+          const float fg = sigmoidf_(acc[1][r] * unscale + xgs[j][1][r]);
+          const float gg = tanhf_(acc[2][r] * unscale + xgs[j][2][r]);
+          const float og = sigmoidf_(acc[3][r] * unscale + xgs[j][3][r]);
+          c[j][r] = fg * c[j][r] + ig * gg;
+          h[j][r] = og * tanhf_(c[j][r]);
+        }
+        hv4[r] = h[j][r];
+      }
+      {
+        uint2 hi, lo;
+        split4(hv4, 16384.f, hi, lo);
+        unsigned char* d = hs + ((cur[j] ^ 1) * LBN + j * LB) * HLS + my_lds;
+        *(uint2*)d = hi;
+        *(uint2*)(d + 16) = lo;
+      }
+      if (active)   // write-through store: the output row AND the hand-off to the other three workgroups
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv4), rec_rsrc,
+                                               (unsigned)((rowi * 512 + dir * 256 + myu) * 4), 0, 16);
+      REC_STAMP(3);
+      __syncthreads();
+      REC_STAMP(5);
+      if (s_fail[j]) return;     // uniform (s_fail[j] is next written two barriers from here)
+      if (xch) cur[o] ^= 1;      // the other tile's next image is complete: its own units (the half-step before) + the chunks
+    }
+    // a tile whose hand-off nobody fetched because it has no further step keeps cur; nothing reads it again
+  }
+  REC_PROF_OUT();
+  // padding rows (t >= T_i) of this workgroup's lines, direction and 64 units: zero instead of the fill pattern
+  for (int ln = 0; ln < LBN; ln++) {
+    const int bb = b0 + ln;
+    if (bb >= B) break;
+    const int Tl = tlen ? tlen[bb] : T;
+    for (int r = Tl * 16 + tid; r < T * 16; r += 256)
+      *(f32x4*)(rec + ((size_t)bb * T + (r >> 4)) * 512 + dir * 256 + part * 64 + (r & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// nt: 1 = lstm_rec_split_h3_kernel (16 lines per group of four workgroups), 2 = lstm_rec_split2_h3_kernel (32 lines)
 void launch_lstm_rec_split_h3(const float* xp, const void* whh3, float* rec, const int32_t* tlen, int B, int T,
-                              float unscale, unsigned* tmo, hipStream_t s) {
-  const int groups = (B + LB - 1) / LB;
+                              float unscale, unsigned* tmo, hipStream_t s, int nt) {
   // tmo: one device word, zeroed by the caller, set to 1 by the kernel when a hand-off timed out.  The output rows double
   // as arrival flags: fill them with a bit pattern no h value has (every row a step can poll must carry it, and with
   // ragged lengths those rows are scattered, so the whole tensor is filled: 37 MB at 256 lines, ~10 us)
   (void)hipMemsetAsync(rec, 0xFF, (size_t)B * T * 512 * sizeof(float), s);
+  if (nt == 2) {
+    const int groups = (B + 2 * LB - 1) / (2 * LB);
+    static const int pk = getenv("CRNN_SPLIT2_PK") ? atoi(getenv("CRNN_SPLIT2_PK")) : 4;
+    if (pk <= 0)
+      hipLaunchKernelGGL(lstm_rec_split2_h3_kernel<0>, dim3(groups * 4, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen, B, T, unscale, tmo);
+    else if (pk < 8)
+      hipLaunchKernelGGL(lstm_rec_split2_h3_kernel<4>, dim3(groups * 4, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen, B, T, unscale, tmo);
+    else
+      hipLaunchKernelGGL(lstm_rec_split2_h3_kernel<8>, dim3(groups * 4, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen, B, T, unscale, tmo);
+    return;
+  }
+  const int groups = (B + LB - 1) / LB;
   hipLaunchKernelGGL(lstm_rec_split_h3_kernel, dim3(groups * 4, 2), dim3(256), 0, s, xp, (const uint4*)whh3, rec, tlen, B,
                      T, unscale, tmo);
 }

@@ -270,18 +270,22 @@ def test_pages_from_two_threads_use_their_own_lanes(golden, zh3):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rec_res", ["1", "0"])
-def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh, rec_res):
+@pytest.mark.parametrize("rec_res,split_nt", [("1", "1"), ("0", "1"), ("1", "2")])
+def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh, rec_res, split_nt):
     """Small batches use the four-workgroups-per-group recurrence (lstm_rec_split_h3_kernel) in the synchronous host paths;
     it must reproduce the one-workgroup kernel of the same arithmetic (lstm_rec_h3_kernel) bit for bit: same logits for
     n = 1, 17, 48 and 200 lines of different widths (lines ending at different steps exercise the keep-old-h path of the
     exchange).  rec_res: the one-workgroup kernel with a quarter of W_hh resident ("1", the default) and streaming all of
-    it ("0"; CRNN_REC_RES is read at every launch)."""
+    it ("0"; CRNN_REC_RES is read at every launch).  split_nt: 16 or 32 lines per group of four workgroups (CRNN_SPLIT_NT, read
+    at every launch; "2" is what pipelined device batches from 128 lines take -- here forced on every batch size, so that
+    groups with one line, with 15 empty rows in the second tile and with ragged lengths all go through it)."""
     from ocr_amd.crnn.network_hip import CRNN
     G, M = golden
     old = os.environ.get("CRNN_LSTM_SPLIT")
     old_res = os.environ.get("CRNN_REC_RES")
+    old_nt = os.environ.get("CRNN_SPLIT_NT")
     os.environ["CRNN_REC_RES"] = rec_res
+    os.environ["CRNN_SPLIT_NT"] = split_nt
     try:
         os.environ["CRNN_LSTM_SPLIT"] = "0"
         ref = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=1)
@@ -314,7 +318,12 @@ def test_hidden_split_recurrence_is_bit_identical(golden, synth_zh, rec_res):
         os.environ.pop("CRNN_REC_RES", None)
     else:
         os.environ["CRNN_REC_RES"] = old_res
+    if old_nt is None:
+        os.environ.pop("CRNN_SPLIT_NT", None)
+    else:
+        os.environ["CRNN_SPLIT_NT"] = old_nt
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[2], b[2])
+    assert spl.split_timeouts() == 0
 
 
 @pytest.mark.gpu
