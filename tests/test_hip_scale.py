@@ -371,7 +371,9 @@ def test_split_recurrences_of_two_handles_on_one_gpu(synth_en):
         ms.append(m)
     rs = np.random.RandomState(13)
     jobs = [[rs.randint(0, 256, size=(32, int(w))).astype(np.uint8) for w in rs.randint(40, 400, size=n)] for n in (30, 70)]
-    batches = [rs.randint(0, 256, size=(96, 32, 200)).astype(np.uint8) for _ in range(2)]
+    # (160 lines: pipelined device batches from 128 lines take the two-tile form, lstm_rec_split2_h3_kernel, the host batches
+    # of 30 and 70 lines the one-tile form -- both forms of both handles share the device's chain)
+    batches = [rs.randint(0, 256, size=(160, 32, 200)).astype(np.uint8) for _ in range(2)]
     want_host = [ms[k].predict_lines(jobs[k], min_cols=1 << 30) for k in range(2)]
     want_dev = [_device_batch(ms[k], batches[k]) for k in range(2)]
     errs = []

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Pipelined-only A/B of environment switches inside one box: tools/ab_env_pipe.sh REPS "A=1" "B=2 C=3" ...
+# (an argument "ARGS:--lanes 3" passes bench.py arguments instead)
 # bench.py --steps 100 with no switch ("base") and with each argument's switches, alternating, REPS times.
 set -e
 R=$1; shift
@@ -7,11 +8,13 @@ mkdir -p gpurun_out/r3x
 for rep in $(seq 1 $R); do
   i=0
   for e in "CRNN_X=1" "$@"; do
-    timeout -k 10 200 env $e python bench.py --no-cpu-baseline --steps 100 > gpurun_out/r3x/ep_${i}_$rep.json 2>>gpurun_out/r3x/err.log
-    python - "$e" $rep gpurun_out/r3x/ep_${i}_$rep.json <<'PY'
+    a=""
+    case "$e" in ARGS:*) a="${e#ARGS:}"; e="CRNN_X=1";; esac     # "ARGS:--lanes 3": bench.py arguments instead of a switch
+    timeout -k 10 200 env $e python bench.py --no-cpu-baseline --steps 100 $a > gpurun_out/r3x/ep_${i}_$rep.json 2>>gpurun_out/r3x/err.log
+    python - "$e" $rep gpurun_out/r3x/ep_${i}_$rep.json "$a" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
-print(sys.argv[1], sys.argv[2], d["value"], d["ms_per_step"], flush=True)
+print(sys.argv[1], sys.argv[4] if len(sys.argv) > 4 else "", sys.argv[2], d["value"], d["ms_per_step"], flush=True)
 PY
     i=$((i+1))
   done
