@@ -6,6 +6,13 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+// Kernels that need more than 256 registers per lane (the compiler then keeps part of them in AccVGPRs) claim the WHOLE
+// register file of their SIMD: a wave of another kernel that shares the SIMD with such a wave makes its results go wrong
+// (round 3, DESIGN.md section 4: found on wino4_out_in_h3_kernel<0> in the pipelined path -- single 4-byte words of V in
+// lanes 12-15 of a row of 16 carried a stale register's contents, once in ~50 batches of 256 lines; gone with this line,
+// 0 in 60 000 batches against 700-800 in 20 000 in the same box).  Costs nothing: no instruction, no register is touched.
+#define CRNN_WHOLE_REGISTER_FILE() asm volatile("" ::: "v255", "a255")
+
 namespace crnn {
 
 // Implicit-GEMM convolution / plain GEMM on the f32 MFMA:

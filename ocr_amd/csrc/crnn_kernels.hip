@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void wino4_in_h3_kernel(const float* __rest
 // columns then rows of B^T d B, 36 float4 stores.
 __global__ __launch_bounds__(256) void wino4_in_kernel(const float* __restrict__ x, float* __restrict__ V,
                                                        int B, int H, int W, int C, long ntile_pad) {
+  CRNN_WHOLE_REGISTER_FILE();
   const int th = H >> 2, tw = (W + 3) >> 2, C4 = C >> 2;
   const long total = (long)B * th * tw * C4;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(256) void wino4_out_pool21_kernel(const float* __re
                                                                const int32_t* __restrict__ wvalid, int B, int H, int W,
                                                                int Co, int act, long ntile_pad, int nseg,
                                                                const float* __restrict__ vs, float us) {
+  CRNN_WHOLE_REGISTER_FILE();
   const int th = H >> 2, tw = (W + 3) >> 2, C4 = Co >> 2, Wp = W + 1, Hp = H >> 1;
   const int seglen = (tw + nseg - 1) / nseg;
   const long total = (long)B * th * nseg * C4;
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(128) void wino4_out_in_h3_kernel(const float* __res
                                                               float* __restrict__ vs_out, int W, int C,
                                                               long ntile_pad_in, long ntile_pad_out, int nseg) {
   __shared__ float wmax[2][2];
+  CRNN_WHOLE_REGISTER_FILE();
   const int C4 = C >> 2, c4 = threadIdx.x, wave = threadIdx.x >> 6;
   const int tw = (W + 3) >> 2;                              // tiles per tile row of layer L
   // width of layer L + 1's input map and its tiles per line (SRC 2: conv6 has Wn - 1 output columns in tiles of 4)
@@ -2509,6 +2512,7 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(const float* __restrict__
                                                        const float* __restrict__ whhp,
                                                        float* __restrict__ rec,
                                                        const int32_t* __restrict__ tlen, int B, int T) {
+  CRNN_WHOLE_REGISTER_FILE();
   __shared__ __attribute__((aligned(16))) float hs[2 * LB * HS];
   const int dir = blockIdx.y, b0 = blockIdx.x * LB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;
@@ -2641,6 +2645,7 @@ template <bool RES>
 __global__ __launch_bounds__(256) void lstm_rec_h3_kernel(const float* __restrict__ xp, const uint4* __restrict__ whh3,
                                                           float* __restrict__ rec, const int32_t* __restrict__ tlen,
                                                           int B, int T, float unscale, const unsigned* __restrict__ gate) {
+  CRNN_WHOLE_REGISTER_FILE();
   // gate != nullptr: run only if *gate != 0 (the repeat of a hidden-split launch that gave up, queued behind it by callers
   // that cannot look at the time-out word themselves: the asynchronous device path)
   if (gate && __builtin_nontemporal_load(gate) == 0u) return;
@@ -2906,6 +2911,7 @@ __global__ __launch_bounds__(256) void lstm_rec_split_h3_kernel(const float* __r
                                                                 const uint4* __restrict__ whh3, float* rec,
                                                                 const int32_t* __restrict__ tlen, int B, int T,
                                                                 float unscale, unsigned* tmo) {
+  CRNN_WHOLE_REGISTER_FILE();
   __shared__ __attribute__((aligned(16))) unsigned char hs[2 * LB * HLS];
   __shared__ int s_fail;
   const int dir = blockIdx.y, grp = blockIdx.x >> 2, part = blockIdx.x & 3, b0 = grp * LB;
@@ -3088,6 +3094,7 @@ __global__ __launch_bounds__(256) void lstm_rec_split2_h3_kernel(const float* __
                                                                  const uint4* __restrict__ whh3, float* rec,
                                                                  const int32_t* __restrict__ tlen, int B, int T,
                                                                  float unscale, unsigned* tmo) {
+  CRNN_WHOLE_REGISTER_FILE();
   constexpr int LBN = 2 * LB;
   __shared__ __attribute__((aligned(16))) unsigned char hs[2 * LBN * HLS];   // [image][tile][line]
   __shared__ int s_fail[2];

@@ -637,6 +637,7 @@ __global__ __launch_bounds__(256) void lstm_rec_bf16_kernel(const float* __restr
                                                             const __bf16* __restrict__ whhp,
                                                             __bf16* __restrict__ rec,
                                                             const int32_t* __restrict__ tlen, int B, int T) {
+  CRNN_WHOLE_REGISTER_FILE();
   __shared__ __attribute__((aligned(16))) __bf16 hs[2 * LB * HSB];
   const int dir = blockIdx.y, b0 = blockIdx.x * LB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, bl = lane & 15;

@@ -43,6 +43,7 @@ def main():
         return 2
     bad = []
     scratch = []
+    agpr_of, vgpr_of = {}, {}
     n_pk = 0
     with tempfile.TemporaryDirectory() as td:
         tmp = os.path.join(td, os.path.basename(lib))
@@ -70,6 +71,7 @@ def main():
             # crnn_forward_device_noalloc promises not to cause -- no kernel of the library may need any
             notes = subprocess.run([LLVM + "/llvm-readobj", "--notes", os.path.join(td, co)], capture_output=True, text=True).stdout
             name = "?"
+            pending_agpr = 0
             for line in notes.splitlines():
                 m = re.match(r"\s*\.name:\s+(\S+)", line)
                 if m:
@@ -77,10 +79,28 @@ def main():
                 m = re.match(r"\s*\.private_segment_fixed_size:\s+(\d+)", line)
                 if m and int(m.group(1)) > 0:
                     scratch.append((name, int(m.group(1))))
+                # a kernel that keeps registers in AccVGPRs (more than 256 per lane) must claim the whole register file
+                # of its SIMD (CRNN_WHOLE_REGISTER_FILE, crnn_kernels.h): beside a wave of another kernel its results
+                # went wrong in the pipelined path
+                # (.agpr_count is the first key of a kernel's record, before its .name: remembered until .vgpr_count, the last)
+                m = re.match(r"\s*-?\s*\.agpr_count:\s+(\d+)", line)
+                if m:
+                    pending_agpr = int(m.group(1))
+                m = re.match(r"\s*\.vgpr_count:\s+(\d+)", line)
+                if m:
+                    vgpr_of[name] = int(m.group(1))
+                    agpr_of[name] = pending_agpr
+                    pending_agpr = 0
     if scratch:
         print("check_isa: %d kernels use scratch memory (register spills or stack arrays):" % len(scratch))
         for k, n in scratch:
             print("  %s   %d bytes per lane" % (k, n))
+        return 1
+    shared = sorted(k for k, a in agpr_of.items() if a > 0 and vgpr_of.get(k, 0) < 512)
+    if shared:
+        print("check_isa: %d kernels use AccVGPRs without claiming the whole register file (CRNN_WHOLE_REGISTER_FILE):" % len(shared))
+        for k in shared:
+            print("  %s   %d registers, %d of them AccVGPRs" % (k, vgpr_of.get(k, 0), agpr_of[k]))
         return 1
     if bad:
         kernels = sorted(set(b[0] for b in bad))
@@ -89,7 +109,8 @@ def main():
             ex = next(b[1] for b in bad if b[0] == k)
             print("  %s   e.g. %s" % (k, ex))
         return 1
-    print("check_isa: ok (%d packed-fp32 instructions, none with op_sel; no kernel uses scratch memory)" % n_pk)
+    print("check_isa: ok (%d packed-fp32 instructions, none with op_sel; no kernel uses scratch memory; %d kernels with AccVGPRs, "
+          "all with the whole register file)" % (n_pk, sum(1 for a in agpr_of.values() if a > 0)))
     return 0
 
 

@@ -1,0 +1,84 @@
+"""Soak of the PIPELINED device path (two lanes, batches queued back to back, no sync): every batch's raw arg-max rows are
+compared on the device with those of a synchronous call on the same input; mismatching (line, timestep) positions are
+listed.  Prints one JSON line; exit status 1 on any mismatch.
+
+    python tools/soak_pipe.py [--batches 20000] [--lines 256] [--width 280] [--lanes 2] [--slots 4]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, default=20000)
+    ap.add_argument("--lines", type=int, default=256)
+    ap.add_argument("--width", type=int, default=280)
+    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--slots", type=int, default=4)
+    args = ap.parse_args()
+    import torch
+    from ocr_amd.crnn import keys
+    from ocr_amd.crnn.network_hip import CRNN
+    from ocr_amd.crnn.synth import synth_state_dict
+    dev = torch.device("cuda", 0)
+    m = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=args.lanes)
+    m.load_state_dict(synth_state_dict(5530, seed=0))
+    n, w, T = args.lines, args.width, args.width // 4 + 1
+    rs = np.random.RandomState(77)
+    inputs = [torch.from_numpy(rs.randint(0, 256, size=(n, 32, w)).astype(np.uint8)).to(dev) for _ in range(args.slots)]
+    want = []
+    for d in inputs:        # synchronous calls: the reference rows (one-tile recurrence, one batch on the device)
+        raw = torch.zeros((n, T), dtype=torch.int32, device=dev)
+        lab = torch.zeros((n, T), dtype=torch.int32, device=dev)
+        ln = torch.zeros((n,), dtype=torch.int32, device=dev)
+        m.forward_device(d.data_ptr(), n, w, lab.data_ptr(), ln.data_ptr(), d_raw_ptr=raw.data_ptr(), sync=True)
+        m.synchronize()
+        want.append(raw.clone())
+    NS = args.lanes + 2
+    outs = [(torch.zeros((n, T), dtype=torch.int32, device=dev), torch.zeros((n, T), dtype=torch.int32, device=dev),
+             torch.zeros((n,), dtype=torch.int32, device=dev)) for _ in range(NS)]
+    ext = [torch.cuda.ExternalStream(m.stream_ptr(l), device=dev) for l in range(args.lanes)]
+    evs = [torch.cuda.Event() for _ in range(NS)]
+    bad = []
+    nbad = 0
+    t0 = time.time()
+
+    def launch(k):
+        s = k % NS
+        lane = m.forward_device(inputs[k % args.slots].data_ptr(), n, w, outs[s][1].data_ptr(), outs[s][2].data_ptr(),
+                                d_raw_ptr=outs[s][0].data_ptr())
+        evs[s].record(ext[lane])
+
+    def check(k):
+        nonlocal nbad
+        s = k % NS
+        evs[s].synchronize()
+        diff = outs[s][0] != want[k % args.slots]
+        if bool(diff.any()):
+            pos = diff.nonzero().cpu().numpy().tolist()
+            nbad += 1
+            if len(bad) < 40:
+                bad.append({"batch": k, "slot": k % args.slots, "positions": pos[:12], "count": len(pos)})
+
+    for k in range(args.batches):
+        launch(k)
+        if k >= args.lanes:
+            check(k - args.lanes)
+    for k in range(max(0, args.batches - args.lanes), args.batches):
+        check(k)
+    print(json.dumps({"batches": args.batches, "lines": n, "width": w, "lanes": args.lanes, "bad_batches": nbad,
+                      "seconds": round(time.time() - t0, 1), "split_timeouts": m.split_timeouts(),
+                      "split_nt": os.environ.get("CRNN_SPLIT_NT", "auto"), "first": bad}))
+    return 1 if nbad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
