@@ -41,3 +41,23 @@ def test_cls_select_beside_mfma_kernels(aggressor):
     assert os.path.exists(TOOL), "tools/corun_test missing: make -C ocr_amd/csrc"
     r = subprocess.run([TOOL, str(aggressor), "1500", "256", "2"], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0 and " 0 of 1500 iterations differ" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split_nt", ["auto", "1"])
+def test_pipelined_batches_soak_equals_synchronous_results(split_nt):
+    """Round 3 found a second way in which kernels of different lanes disturb each other: a kernel that keeps registers in
+    AccVGPRs (more than 256 per lane: the chained Winograd transforms, the recurrences) returned a few wrong words when a wave
+    of another kernel shared its SIMD -- one wrong line in 70 to 800 pipelined batches of 256, never with one batch on the
+    device at a time, so the 48-batch tests did not see it.  Such kernels now claim the whole register file
+    (CRNN_WHOLE_REGISTER_FILE; tools/check_isa.py fails the build otherwise).  tools/soak_pipe.py queues batches back to back
+    on two lanes and compares every batch's raw arg-max rows with a synchronous call's: 5000 batches here (before the fix
+    20 to 200 of them were wrong, depending on the box); DESIGN.md has the 100 000-batch runs.  split_nt: the recurrence form
+    of the pipelined path (auto = two row tiles per group from 128 lines) and the one-tile form."""
+    env = dict(os.environ)
+    if split_nt != "auto":
+        env["CRNN_SPLIT_NT"] = split_nt
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_pipe.py"), "--batches", "5000"], capture_output=True,
+                       text=True, timeout=170, env=env)
+    assert r.returncode == 0 and '"bad_batches": 0' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '"split_timeouts": 0' in r.stdout
