@@ -2,7 +2,7 @@
 compared on the device with those of a synchronous call on the same input; mismatching (line, timestep) positions are
 listed.  Prints one JSON line; exit status 1 on any mismatch.
 
-    python tools/soak_pipe.py [--batches 20000] [--lines 256] [--width 280] [--lanes 2] [--slots 4]
+    python tools/soak_pipe.py [--batches 20000] [--lines 256] [--width 280] [--lanes 2] [--slots 4] [--precision fp32|bf16]
 """
 import argparse
 import json
@@ -23,13 +23,14 @@ def main():
     ap.add_argument("--width", type=int, default=280)
     ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--precision", default="fp32")
     args = ap.parse_args()
     import torch
     from ocr_amd.crnn import keys
     from ocr_amd.crnn.network_hip import CRNN
     from ocr_amd.crnn.synth import synth_state_dict
     dev = torch.device("cuda", 0)
-    m = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=args.lanes)
+    m = CRNN(32, 1, 5530, 256, alphabet=keys.alphabetChinese, device=0, lanes=args.lanes, precision=args.precision)
     m.load_state_dict(synth_state_dict(5530, seed=0))
     n, w, T = args.lines, args.width, args.width // 4 + 1
     rs = np.random.RandomState(77)
@@ -74,7 +75,7 @@ def main():
             check(k - args.lanes)
     for k in range(max(0, args.batches - args.lanes), args.batches):
         check(k)
-    print(json.dumps({"batches": args.batches, "lines": n, "width": w, "lanes": args.lanes, "bad_batches": nbad,
+    print(json.dumps({"batches": args.batches, "lines": n, "width": w, "lanes": args.lanes, "precision": args.precision, "bad_batches": nbad,
                       "seconds": round(time.time() - t0, 1), "split_timeouts": m.split_timeouts(),
                       "split_nt": os.environ.get("CRNN_SPLIT_NT", "auto"), "first": bad}))
     return 1 if nbad else 0
