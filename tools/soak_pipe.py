@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--nclass", type=int, default=5530, help="5530: the Chinese head, 65: the English head")
+    ap.add_argument("--host-compare", type=int, default=0, help="1: copy every batch's rows back and compare on the host (no "
+                    "comparison kernels of torch beside the library's kernels on the device)")
     ap.add_argument("--ragged", type=int, default=0, help="1: per-line valid widths (random, multiples of 4) in every batch")
     args = ap.parse_args()
     import torch
@@ -49,6 +51,7 @@ def main():
         m.forward_device(d.data_ptr(), n, w, lab.data_ptr(), ln.data_ptr(), d_raw_ptr=raw.data_ptr(), widths=wd, sync=True)
         m.synchronize()
         want.append((raw.clone(), lab.clone(), ln.clone()))
+    want_host = [x[0].cpu().numpy() for x in want]
     NS = args.lanes + 2
     outs = [(torch.zeros((n, T), dtype=torch.int32, device=dev), torch.zeros((n, T), dtype=torch.int32, device=dev),
              torch.zeros((n,), dtype=torch.int32, device=dev)) for _ in range(NS)]
@@ -69,7 +72,12 @@ def main():
         s = k % NS
         evs[s].synchronize()
         wr, wl, wn = want[k % args.slots]
-        if args.ragged:      # compare what is defined for a ragged batch: the collapsed labels up to each line's length
+        if args.host_compare and not args.ragged:
+            got = outs[s][0].cpu().numpy()          # (a copy engine transfer: no kernel)
+            wh = want_host[k % args.slots]
+            ok = bool(np.array_equal(got, wh))
+            diff = torch.from_numpy(got != wh) if not ok else None
+        elif args.ragged:      # compare what is defined for a ragged batch: the collapsed labels up to each line's length
             ok = bool((outs[s][2] == wn).all())
             if ok:
                 msk = torch.arange(T, device=dev)[None, :] < wn[:, None]
