@@ -148,8 +148,11 @@ CRNN_API int crnn_predict_page(crnn_handle* h, const uint8_t* page, int32_t heig
  * width-bucketing scheduler and bench.py use): d_gray uint8 [n,32,w] device pointer; widths
  * host int32[n] (valid width of each line, <= w) or NULL when every line is w wide.
  * Outputs are DEVICE pointers: d_lab [n,T] int32, d_len [n] int32, d_raw [n,T] int32 or NULL,
- * with T = crnn_out_len(w).  Runs asynchronously unless sync != 0 (a sync call of up to 512 lines also gets the
- * latency form of the LSTM recurrence, like the host paths: same results bit for bit).  Successive calls rotate over
+ * with T = crnn_out_len(w).  Runs asynchronously unless sync != 0.  Up to 512 lines the LSTM recurrence runs in its
+ * hidden-split form either way, like the host paths (synchronous calls: 16 lines per group of four workgroups, the
+ * lowest latency; asynchronous calls from 128 lines: 32 lines per group, half the workgroups, and a repeat with the
+ * one-workgroup kernel queued behind it that only runs if a hand-off timed out): the same results bit for bit.
+ * Successive calls rotate over
  * the handle's lanes (crnn_config.lanes): the call returns the lane index (>= 0) it was queued
  * on, whose stream is crnn_stream(h, lane); work on different lanes overlaps on the device.
  * No reference counterpart (the reference never keeps data on a device). */
@@ -185,9 +188,10 @@ CRNN_API int crnn_forward_device_noalloc(crnn_handle* h, const uint8_t* d_gray, 
 /* Workspace bytes a batch of n lines of padded width w needs (what _noalloc compares with the limit). */
 CRNN_API int64_t crnn_noalloc_workspace_bytes(const crnn_handle* h, int32_t n, int32_t w);
 
-/* Number of times the hidden-split recurrence (small synchronous batches) gave up waiting for its partner
- * workgroups on this handle and the batch was repeated with the one-workgroup kernel (a latency cliff a
- * service wants to see; 0 in normal operation).  No reference counterpart. */
+/* Number of times the hidden-split recurrence (batches of up to 512 lines) gave up waiting for its partner
+ * workgroups on this handle and the layer was repeated with the one-workgroup kernel, repeats made on the device
+ * by asynchronous calls included (a latency cliff a service wants to see; 0 in normal operation).  No reference
+ * counterpart. */
 CRNN_API int64_t crnn_split_timeouts(const crnn_handle* h);
 
 /* Diagnostic: the load-time channel equalisation's factors (crnn_load_weights rescales every hidden channel by an exact
