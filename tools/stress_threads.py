@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=3)
     ap.add_argument("--own-handle", type=int, default=0, help="1: every thread has a model object of its own")
     ap.add_argument("--shuffle", type=int, default=0, help="each thread visits its crops in a random order (seed)")
+    ap.add_argument("--torch-noise", type=int, default=0, help="1: one more thread keeps small torch kernels (element-wise "
+                    "compare + reduction on a stream of its own) on the device, the neighbours that exposed the AccVGPR "
+                    "co-run fault of round 3 (DESIGN.md section 4)")
     args = ap.parse_args()
     from ocr_amd.crnn import keys
     from ocr_amd.crnn.network_hip import CRNN
@@ -62,14 +65,35 @@ def main():
                         return
                 prev = i
 
+    stop = []
+    noise_n = [0]
+
+    def noise():
+        import torch
+        dev = torch.device("cuda", 0)
+        a = torch.zeros((256, 71), dtype=torch.int32, device=dev)
+        b = torch.zeros((256, 71), dtype=torch.int32, device=dev)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            while not stop:
+                for _ in range(50):
+                    (a != b).any()
+                torch.cuda.current_stream().synchronize()
+                noise_n[0] += 50
+
     t0 = time.time()
     th = [threading.Thread(target=work, args=(k,)) for k in range(args.threads)]
+    nt = threading.Thread(target=noise) if args.torch_noise else None
+    if nt:
+        nt.start()
     for t in th:
         t.start()
     for t in th:
         t.join()
+    stop.append(1)
+    if nt:
+        nt.join()
     out = {"threads": args.threads, "lanes": args.lanes, "calls": sum(calls), "mismatches": len(bad),
-           "seconds": round(time.time() - t0, 2), "first": bad[:3]}
+           "seconds": round(time.time() - t0, 2), "first": bad[:3], "torch_noise_kernels": 2 * noise_n[0]}
     if hasattr(m, "split_timeouts"):
         try:
             out["split_timeouts"] = int(m.split_timeouts())
