@@ -48,8 +48,10 @@ def test_cls_select_beside_mfma_kernels(aggressor):
 def test_pipelined_batches_soak_equals_synchronous_results(split_nt):
     """Round 3 found a second way in which kernels of different lanes disturb each other: a kernel that keeps registers in
     AccVGPRs (more than 256 per lane: the chained Winograd transforms, the recurrences) returned a few wrong words when a wave
-    of another kernel shared its SIMD -- one wrong line in 70 to 800 pipelined batches of 256, never with one batch on the
-    device at a time, so the 48-batch tests did not see it.  Such kernels now claim the whole register file
+    of another kernel shared its SIMD -- one wrong line in 70 to 800 pipelined batches of 256 when small kernels of a third
+    stream are on the device too (this soak's own comparison kernels are: with the comparison on the host the old build showed
+    nothing in 60 000 batches, and the product-only 2M-line job 3 wrong lines in 33 M), never with one batch on the device at
+    a time, so the 48-batch tests did not see it.  Such kernels now claim the whole register file
     (CRNN_WHOLE_REGISTER_FILE; tools/check_isa.py fails the build otherwise).  tools/soak_pipe.py queues batches back to back
     on two lanes and compares every batch's raw arg-max rows with a synchronous call's: 5000 batches here (before the fix
     20 to 200 of them were wrong, depending on the box); DESIGN.md has the 100 000-batch runs.  split_nt: the recurrence form
